@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mcells*iter/s of the Jacobi sweep at 4096^2 on MI355X.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = `--sweeps-per-step` weighted-Jacobi sweeps plus one Deff evaluation
+(wall fluxes) of one synthetic two-phase image (SURVEY.md 8d generator) that is
+already resident in HBM.  With N > 1 every rank solves its own image (image
+index = rank): the path shards as whole images, there is no data-path
+collective, scaling is weak.  Rank 0 prints ONE JSON line.
+
+roofline: algorithmic bytes = 64 B per cell per sweep (A 5x8 + b 8 + x 8 read,
+xNew 8 written: the operator behind the reference's seam) x
+cells x sweeps per launch, divided by the sweep kernel's average launch duration
+measured with HIP events on the solver's own stream inside deff_sweeps().
+cpu_baseline: the single-thread CPU oracle on a bounded sample of the same
+workload (rank 0, N = 1 only); a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+BYTES_PER_CELL_SWEEP = 64.0
+
+
+def cpu_baseline(n, seconds_target=12.0):
+    """Single-thread oracle sweep rate on the same synthetic workload (bounded sample)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    ob.build()
+    pix = ob.synth_mask(n, n, 12345, 0)
+    D = ob.fill_D_2phase(pix, 1.0, 1e-3)
+    A, b = ob.discretize(D, 0.0, 1.0)
+    x = ob.linear_guess(n, n, 0.0, 1.0)
+    t0 = time.perf_counter()
+    x = ob.sweeps(A, b, x, 2)
+    per = (time.perf_counter() - t0) / 2
+    k = max(2, min(2000, int(seconds_target / max(per, 1e-9))))
+    t0 = time.perf_counter()
+    ob.sweeps(A, b, x, k)
+    dt = time.perf_counter() - t0
+    return {"value": n * n * k / dt / 1e6, "unit": "Mcells*iter/s", "cores": 1, "kind": "port",
+            "sample": f"{k} sweeps of the {n}x{n} synthetic image, oracle/deff_oracle.c (gcc -O2, AoS, 1 thread), "
+                      f"host has {os.cpu_count()} logical CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--sweeps-per-step", type=int, default=1000)
+    ap.add_argument("--kernel", default="auto", choices=["auto", "explicit", "scalar", "matfree", "matfree_tb"])
+    ap.add_argument("--omega", type=float, default=2.0 / 3.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], help="key=value tuning knob (repeatable)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch  # first: one HIP runtime for torch and libdeff_amd
+    import torch.distributed as dist
+    import effectivediffusivityfvm_amd as pkg
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    n, S = args.size, args.sweeps_per_step
+    s = pkg.Solver(n, n, device=local_rank, kernel=args.kernel)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        s.set_tuning(k, int(v))
+    s.synth_image(12345, rank)                  # image index = rank: independent images, no comm
+    s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+    s.init_linear(0.0, 1.0)
+
+    def step():
+        ms = s.sweeps(S, args.omega)
+        deff, _, _ = s.flux()
+        return ms, deff
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    deff = float("nan")
+    for _ in range(args.steps):
+        ms, deff = step()
+        kernel_ms += ms
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        cells = float(n) * n
+        launches = args.steps * S
+        launch_s = kernel_ms * 1e-3 / launches            # avg duration of one sweep launch (HIP events)
+        achieved = BYTES_PER_CELL_SWEEP * cells / launch_s / 1e9
+        out = {
+            "metric": "Mcells*iter/s (Jacobi sweep) at 4096^2" if n == 4096 else f"Mcells*iter/s (Jacobi sweep) at {n}^2",
+            "value": world * cells * S * args.steps / elapsed / 1e6,
+            "unit": "Mcells*iter/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n}x{n} synthetic two-phase image (splitmix64 seed 12345, porosity 0.5), Ds=1e-3 Df=1 "
+                            f"CL=0 CR=1, omega={args.omega:.6g}; step = {S} sweeps + 1 Deff evaluation; "
+                            f"one image per GPU (image index = rank)",
+                "kernel": s.kernel_in_use(),
+                "sweeps_per_step": S,
+                "deff_raw_after_run": deff,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": s.kernel_in_use(),
+                "launch_us": launch_s * 1e6,
+                "algorithmic_bytes_per_launch": BYTES_PER_CELL_SWEEP * cells,
+            },
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                tr = json.load(open(traffic_file)).get(f"{s.kernel_in_use()}_{n}")
+                if tr:
+                    out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = tr.get("source")
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n)
+        print(json.dumps(out), flush=True)
+    s.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+"""ctypes binding of libdeff_amd.so (include/deff_amd.h).
+
+There is no CPU fallback: if the HIP library is missing this module raises at
+load time, and every entry point raises DeffError on a non-zero return code.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libdeff_amd.so")
+
+KERNEL_AUTO, KERNEL_EXPLICIT, KERNEL_SCALAR, KERNEL_MATFREE, KERNEL_MATFREE_TB = range(5)
+KERNEL_NAMES = {"auto": 0, "explicit": 1, "scalar": 2, "matfree": 3, "matfree_tb": 4}
+
+# every symbol include/deff_amd.h declares (tests check the library exports them all)
+SYMBOLS = [
+    "deff_version", "deff_last_error", "deff_error_string", "deff_device_count",
+    "deff_create", "deff_destroy", "deff_mesh", "deff_set_kernel", "deff_get_kernel",
+    "deff_set_tuning", "deff_set_image", "deff_synth_image", "deff_get_image",
+    "deff_assemble_2phase", "deff_assemble_from_D", "deff_set_system", "deff_get_system",
+    "deff_init_linear", "deff_set_field", "deff_get_field", "deff_solve", "deff_sweeps",
+    "deff_flux", "deff_device_field", "deff_synchronize",
+]
+
+
+class DeffError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"deff_amd error {code}: {msg}")
+        self.code = code
+
+
+class Result(C.Structure):
+    _fields_ = [("iters", C.c_int64), ("checks", C.c_int64), ("deff_raw", C.c_double),
+                ("conv", C.c_double), ("loop_ms", C.c_double)]
+
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+_lib = None
+
+
+def load():
+    """Load libdeff_amd.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C effectivediffusivityfvm_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    ctx = C.c_void_p
+    L.deff_version.restype = C.c_char_p
+    L.deff_last_error.restype = C.c_char_p
+    L.deff_error_string.restype = C.c_char_p
+    L.deff_error_string.argtypes = [C.c_int]
+    L.deff_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.deff_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(ctx)]
+    L.deff_destroy.argtypes = [ctx]
+    L.deff_mesh.argtypes = [ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                            C.POINTER(C.c_double)]
+    L.deff_set_kernel.argtypes = [ctx, C.c_int]
+    L.deff_get_kernel.argtypes = [ctx, C.POINTER(C.c_int)]
+    L.deff_set_tuning.argtypes = [ctx, C.c_char_p, C.c_int]
+    L.deff_set_image.argtypes = [ctx, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.deff_synth_image.argtypes = [ctx, C.c_uint64, C.c_uint64]
+    L.deff_get_image.argtypes = [ctx, _u8p]
+    L.deff_assemble_2phase.argtypes = [ctx, C.c_double, C.c_double, C.c_double, C.c_double]
+    L.deff_assemble_from_D.argtypes = [ctx, _dp, C.c_void_p, C.c_double, C.c_double]
+    L.deff_set_system.argtypes = [ctx, _dp, _dp, C.c_void_p, C.c_double, C.c_double]
+    L.deff_get_system.argtypes = [ctx, _dp, _dp]
+    L.deff_init_linear.argtypes = [ctx, C.c_double, C.c_double]
+    L.deff_set_field.argtypes = [ctx, _dp]
+    L.deff_get_field.argtypes = [ctx, _dp]
+    L.deff_solve.argtypes = [ctx, C.c_double, C.c_double, C.c_int64, C.c_int64, C.POINTER(Result),
+                             C.c_void_p, C.c_void_p]
+    L.deff_sweeps.argtypes = [ctx, C.c_int64, C.c_double, C.POINTER(C.c_float)]
+    L.deff_flux.argtypes = [ctx, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
+    L.deff_device_field.argtypes = [ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.deff_synchronize.argtypes = [ctx]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int:
+            pass
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise DeffError(rc, load().deff_last_error().decode("utf-8", "replace"))

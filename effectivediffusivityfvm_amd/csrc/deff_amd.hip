@@ -1,0 +1,743 @@
+// deff_amd.hip -- solver context and C ABI (include/deff_amd.h) of the
+// MI355X-native effective-diffusivity hot path.  Host side of the path the
+// reference implements in Deff2DGPU/Deff2D.cuh: DiscretizeMatrix2D (cuh:815-902),
+// initializeGPU/unInitializeGPU (cuh:904-1021), JacobiGPU (cuh:1163-1314).
+//
+// Design: one context per GPU owns every buffer and a private
+// HIP stream; the image is uploaded as bytes (1 B/pixel) and everything else is
+// produced on the device; sweeps are enqueued back to back with pointer
+// ping-pong (no per-sweep sync or D2D copy, unlike cuh:1239/cuh:1281); a
+// convergence check moves 16*ny bytes, not the field (cuh:1245).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/deff_amd.h"
+#include "fvm_row.hpp"
+#include "kernels_setup.hpp"
+#include "kernels_sweep.hpp"
+
+using namespace deff;
+
+// ------------------------------------------------------------- errors -----
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail(e_ == hipErrorOutOfMemory ? DEFF_ENOMEM : DEFF_EHIP,             \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                       \
+    } while (0)
+
+#define TRY(expr)                  \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != DEFF_OK) return rc_; \
+    } while (0)
+
+// ------------------------------------------------------------ context -----
+
+struct deff_ctx {
+    int device = 0;
+    int nx = 0, ny = 0;
+    size_t n = 0;
+    double dx = 0, dy = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // image (pixels as decoded, W x H, before mesh amplification)
+    uint8_t *pix = nullptr;
+    int W = 0, H = 0, ampX = 1, ampY = 1;
+    bool have_image = false;
+
+    // explicit SoA system
+    double *a0 = nullptr, *c0 = nullptr, *aW = nullptr, *aE = nullptr, *aS = nullptr, *aN = nullptr,
+           *b = nullptr;
+    bool have_explicit = false;
+    double c0_omega = NAN;          // omega the c0 plane was built for
+
+    // matrix-free system
+    uint8_t *code = nullptr;
+    double *lut = nullptr;          // device copy of the tables
+    std::vector<double> lut_a0;     // host: A0 plane per class/code (c0 = w/A0 on demand)
+    std::vector<double> lut_host;   // host: full tables
+    bool have_matfree = false;
+    double lut_omega = NAN;
+    double Ds = 0, Df = 0;          // phase diffusivities of the native 2-phase system
+
+    // wall data for the flux evaluation
+    double *Dl = nullptr, *Dr = nullptr;
+    double CL = 0, CR = 0;
+    bool have_walls = false;
+    double *mf = nullptr;           // device: 2*ny fluxes
+    double *mf_host = nullptr;      // pinned
+
+    // field, ping-pong
+    double *x[2] = {nullptr, nullptr};
+    int cur = 0;
+    bool have_field = false;
+
+    // scratch for chunked uploads (AoS import, D upload)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+
+    int kernel = DEFF_KERNEL_AUTO;
+    int rows_explicit = 0, rows_matfree = 0;     // 0 = default
+};
+
+static int use_device(const deff_ctx *c)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    return DEFF_OK;
+}
+
+template <typename T>
+static int dev_alloc(T **p, size_t count)
+{
+    if (*p) return DEFF_OK;
+    HIP_TRY(hipMalloc((void **)p, count * sizeof(T)));
+    return DEFF_OK;
+}
+
+static int ensure_scratch(deff_ctx *c, size_t bytes)
+{
+    if (c->scratch_bytes >= bytes) return DEFF_OK;
+    if (c->scratch) { HIP_TRY(hipFree(c->scratch)); c->scratch = nullptr; c->scratch_bytes = 0; }
+    HIP_TRY(hipMalloc(&c->scratch, bytes));
+    c->scratch_bytes = bytes;
+    return DEFF_OK;
+}
+
+static int ensure_explicit(deff_ctx *c)
+{
+    TRY(dev_alloc(&c->a0, c->n)); TRY(dev_alloc(&c->c0, c->n));
+    TRY(dev_alloc(&c->aW, c->n)); TRY(dev_alloc(&c->aE, c->n));
+    TRY(dev_alloc(&c->aS, c->n)); TRY(dev_alloc(&c->aN, c->n));
+    TRY(dev_alloc(&c->b, c->n));
+    return DEFF_OK;
+}
+
+static int ensure_walls(deff_ctx *c)
+{
+    TRY(dev_alloc(&c->Dl, (size_t)c->ny));
+    TRY(dev_alloc(&c->Dr, (size_t)c->ny));
+    TRY(dev_alloc(&c->mf, (size_t)2 * c->ny));
+    if (!c->mf_host) HIP_TRY(hipHostMalloc((void **)&c->mf_host, sizeof(double) * 2 * c->ny));
+    return DEFF_OK;
+}
+
+static inline int grid_for(size_t n, int cap = 16384)
+{
+    size_t g = (n + 255) / 256;
+    return (int)(g < (size_t)cap ? (g ? g : 1) : (size_t)cap);
+}
+
+static CoefSoA soa_of(deff_ctx *c) { return CoefSoA{c->a0, c->aW, c->aE, c->aS, c->aN, c->b}; }
+
+// ---------------------------------------------------------- library -------
+
+extern "C" const char *deff_version(void) { return "deff_amd 0.1 (gfx950)"; }
+extern "C" const char *deff_last_error(void) { return g_err; }
+extern "C" const char *deff_error_string(int code)
+{
+    switch (code) {
+    case DEFF_OK: return "ok";
+    case DEFF_EINVAL: return "invalid argument";
+    case DEFF_EHIP: return "HIP runtime error";
+    case DEFF_ENOMEM: return "out of memory";
+    case DEFF_ENODEV: return "no usable device";
+    case DEFF_ESTATE: return "system or field not set";
+    case DEFF_ECOMM: return "RCCL error";
+    default: return "unknown error";
+    }
+}
+
+extern "C" int deff_device_count(int *count)
+{
+    if (!count) return fail(DEFF_EINVAL, "count is NULL");
+    int k = 0;
+    hipError_t e = hipGetDeviceCount(&k);
+    if (e != hipSuccess) { *count = 0; return fail(DEFF_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = k;
+    return DEFF_OK;
+}
+
+// -------------------------------------------------------- lifecycle -------
+
+extern "C" int deff_create(int device, int nx, int ny, deff_ctx **out)
+{
+    if (!out) return fail(DEFF_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (nx < 2 || ny < 2) return fail(DEFF_EINVAL, "mesh must be at least 2x2 (got %dx%d)", nx, ny);
+    if ((size_t)nx * (size_t)ny > (size_t)1 << 31)
+        return fail(DEFF_EINVAL, "mesh %dx%d exceeds 2^31 cells", nx, ny);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(DEFF_ENODEV, "no HIP device (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(DEFF_EINVAL, "device %d out of range [0,%d)", device, count);
+
+    deff_ctx *c = new (std::nothrow) deff_ctx();
+    if (!c) return fail(DEFF_ENOMEM, "host allocation failed");
+    c->device = device;
+    c->nx = nx; c->ny = ny; c->n = (size_t)nx * ny;
+    c->dx = 1.0 / nx;           // cuh:1910-1911: the domain is always the unit square
+    c->dy = 1.0 / ny;
+    int rc = DEFF_OK;
+    do {
+        if ((rc = use_device(c)) != DEFF_OK) break;
+        hipError_t he;
+        if ((he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+            (he = hipEventCreate(&c->ev0)) != hipSuccess || (he = hipEventCreate(&c->ev1)) != hipSuccess) {
+            rc = fail(DEFF_EHIP, "stream/event creation failed: %s", hipGetErrorString(he));
+            break;
+        }
+        if ((rc = dev_alloc(&c->x[0], c->n)) != DEFF_OK) break;
+        if ((rc = dev_alloc(&c->x[1], c->n)) != DEFF_OK) break;
+        // the reference zero-fills its device arrays (cuh:946-973)
+        if (hipMemsetAsync(c->x[0], 0, sizeof(double) * c->n, c->stream) != hipSuccess ||
+            hipMemsetAsync(c->x[1], 0, sizeof(double) * c->n, c->stream) != hipSuccess) {
+            rc = fail(DEFF_EHIP, "memset failed");
+            break;
+        }
+    } while (0);
+    if (rc != DEFF_OK) { deff_destroy(c); return rc; }
+    *out = c;
+    return DEFF_OK;
+}
+
+extern "C" int deff_destroy(deff_ctx *c)
+{
+    if (!c) return DEFF_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *bufs[] = {c->pix, c->a0, c->c0, c->aW, c->aE, c->aS, c->aN, c->b, c->code, c->lut,
+                    c->Dl, c->Dr, c->mf, c->x[0], c->x[1], c->scratch};
+    for (void *p : bufs) if (p) (void)hipFree(p);
+    if (c->mf_host) (void)hipHostFree(c->mf_host);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;                      // no hipDeviceReset (the reference resets per image, cuh:1015)
+    return DEFF_OK;
+}
+
+extern "C" int deff_mesh(const deff_ctx *c, int *nx, int *ny, double *dx, double *dy)
+{
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    if (nx) *nx = c->nx;
+    if (ny) *ny = c->ny;
+    if (dx) *dx = c->dx;
+    if (dy) *dy = c->dy;
+    return DEFF_OK;
+}
+
+extern "C" int deff_set_kernel(deff_ctx *c, int kernel)
+{
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    if (kernel < DEFF_KERNEL_AUTO || kernel > DEFF_KERNEL_MATFREE_TB)
+        return fail(DEFF_EINVAL, "unknown kernel id %d", kernel);
+    c->kernel = kernel;
+    return DEFF_OK;
+}
+
+// Which kernel a sweep will use, given what has been assembled.
+static int resolve_kernel(const deff_ctx *c, int *k)
+{
+    int want = c->kernel;
+    if (want == DEFF_KERNEL_MATFREE_TB) want = DEFF_KERNEL_MATFREE;   // TB lands in a later revision
+    if (want == DEFF_KERNEL_AUTO) want = c->have_matfree ? DEFF_KERNEL_MATFREE : DEFF_KERNEL_EXPLICIT;
+    if (want == DEFF_KERNEL_MATFREE) {
+        if (!c->have_matfree) return fail(DEFF_ESTATE, "matrix-free kernel needs deff_assemble_2phase()");
+    } else {
+        if (!c->have_explicit && !c->have_matfree) return fail(DEFF_ESTATE, "no system assembled");
+        if (want == DEFF_KERNEL_EXPLICIT && (c->nx & 1)) want = DEFF_KERNEL_SCALAR;   // 16-B rows need even nx
+    }
+    *k = want;
+    return DEFF_OK;
+}
+
+extern "C" int deff_get_kernel(const deff_ctx *c, int *k)
+{
+    if (!c || !k) return fail(DEFF_EINVAL, "NULL argument");
+    return resolve_kernel(c, k);
+}
+
+extern "C" int deff_set_tuning(deff_ctx *c, const char *key, int value)
+{
+    if (!c || !key) return fail(DEFF_EINVAL, "NULL argument");
+    if (value < 0) return fail(DEFF_EINVAL, "tuning value must be >= 0");
+    if (!strcmp(key, "rows_explicit")) c->rows_explicit = value;
+    else if (!strcmp(key, "rows_matfree")) c->rows_matfree = value;
+    else return fail(DEFF_EINVAL, "unknown tuning key '%s'", key);
+    return DEFF_OK;
+}
+
+// ------------------------------------------------------------ image -------
+
+static int image_shape(deff_ctx *c, int W, int H, int ampX, int ampY)
+{
+    if (W < 1 || H < 1 || ampX < 1 || ampY < 1)            // cuh:1901-1904
+        return fail(DEFF_EINVAL, "image %dx%d / mesh amplification %dx%d invalid", W, H, ampX, ampY);
+    if ((long long)W * ampX != c->nx || (long long)H * ampY != c->ny)
+        return fail(DEFF_EINVAL, "image %dx%d x amp %dx%d does not match mesh %dx%d", W, H, ampX, ampY,
+                    c->nx, c->ny);
+    if (c->pix && (c->W != W || c->H != H)) { HIP_TRY(hipFree(c->pix)); c->pix = nullptr; }
+    TRY(dev_alloc(&c->pix, (size_t)W * H));
+    c->W = W; c->H = H; c->ampX = ampX; c->ampY = ampY;
+    return DEFF_OK;
+}
+
+extern "C" int deff_set_image(deff_ctx *c, const uint8_t *pix, int W, int H, int ampX, int ampY)
+{
+    if (!c || !pix) return fail(DEFF_EINVAL, "NULL argument");
+    TRY(use_device(c));
+    TRY(image_shape(c, W, H, ampX, ampY));
+    HIP_TRY(hipMemcpyAsync(c->pix, pix, (size_t)W * H, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_image = true;
+    c->have_matfree = false;
+    return DEFF_OK;
+}
+
+extern "C" int deff_synth_image(deff_ctx *c, uint64_t seed, uint64_t img)
+{
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    TRY(use_device(c));
+    TRY(image_shape(c, c->nx, c->ny, 1, 1));
+    hipLaunchKernelGGL(k_synth_mask, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->nx, c->ny,
+                       seed, img);
+    HIP_TRY(hipGetLastError());
+    c->have_image = true;
+    c->have_matfree = false;
+    return DEFF_OK;
+}
+
+extern "C" int deff_get_image(deff_ctx *c, uint8_t *pix)
+{
+    if (!c || !pix) return fail(DEFF_EINVAL, "NULL argument");
+    if (!c->have_image) return fail(DEFF_ESTATE, "no image set");
+    TRY(use_device(c));
+    HIP_TRY(hipMemcpyAsync(pix, c->pix, (size_t)c->W * c->H, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DEFF_OK;
+}
+
+// --------------------------------------------------------- assembly -------
+
+// Tables for the matrix-free kernels: for every position class and phase code,
+// the matrix row fvm_row() would produce.  Built on the host with the same
+// routine the device assembly uses, so they hold the very same doubles.
+static void build_lut_rows(deff_ctx *c, double Ds, double Df, double CL, double CR)
+{
+    c->lut_host.assign(LUT_DOUBLES, 0.0);
+    c->lut_a0.assign(LUT_PLANE_STRIDE, 0.0);
+    for (int ycls = 0; ycls < 3; ++ycls)
+        for (int xcls = 0; xcls < 3; ++xcls)
+            for (int code = 0; code < LUT_CODES; ++code) {
+                auto D = [&](int bit) { return ((code >> bit) & 1) ? Ds : Df; };
+                FvmRow r = fvm_row(D(0), D(1), D(2), D(3), D(4), xcls, ycls, c->dx, c->dy, CL, CR);
+                const int idx = (ycls * 3 + xcls) * LUT_CODES + code;
+                c->lut_a0[idx] = r.a0;
+                c->lut_host[1 * LUT_PLANE_STRIDE + idx] = r.aW;
+                c->lut_host[2 * LUT_PLANE_STRIDE + idx] = r.aE;
+                c->lut_host[3 * LUT_PLANE_STRIDE + idx] = r.aS;
+                c->lut_host[4 * LUT_PLANE_STRIDE + idx] = r.aN;
+                c->lut_host[5 * LUT_PLANE_STRIDE + idx] = r.b;
+            }
+    c->lut_omega = NAN;
+}
+
+static int upload_lut(deff_ctx *c, double omega)
+{
+    if (c->lut_omega == omega) return DEFF_OK;
+    for (int i = 0; i < LUT_PLANE_STRIDE; ++i) c->lut_host[i] = omega / c->lut_a0[i];
+    TRY(dev_alloc(&c->lut, (size_t)LUT_DOUBLES));
+    HIP_TRY(hipMemcpyAsync(c->lut, c->lut_host.data(), sizeof(double) * LUT_DOUBLES, hipMemcpyHostToDevice,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // lut_host may be rewritten by the next call
+    c->lut_omega = omega;
+    return DEFF_OK;
+}
+
+extern "C" int deff_assemble_2phase(deff_ctx *c, double Ds, double Df, double CL, double CR)
+{
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    if (!c->have_image) return fail(DEFF_ESTATE, "deff_assemble_2phase needs an image");
+    TRY(use_device(c));
+    TRY(ensure_walls(c));
+    c->CL = CL; c->CR = CR;
+    hipLaunchKernelGGL(k_wall_D_2phase, dim3((c->ny + 255) / 256), dim3(256), 0, c->stream, c->pix, c->W,
+                       c->ampX, c->ampY, c->nx, c->ny, Df, Ds, c->Dl, c->Dr);
+    HIP_TRY(hipGetLastError());
+    c->have_walls = true;
+
+    // matrix-free form: 1 byte per cell + lookup tables
+    TRY(dev_alloc(&c->code, c->n));
+    hipLaunchKernelGGL(k_phase_codes, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->W, c->ampX,
+                       c->ampY, c->nx, c->ny, c->code);
+    HIP_TRY(hipGetLastError());
+    build_lut_rows(c, Ds, Df, CL, CR);
+    c->have_matfree = true;
+
+    // the explicit SoA planes are built on demand (explicit_from_image)
+    c->Ds = Ds; c->Df = Df;
+    c->have_explicit = false;
+    return DEFF_OK;
+}
+
+// Explicit SoA planes for the native 2-phase system: D from the pixels
+// (cuh:1988-2000), then the general assembly.  Only needed when an explicit
+// kernel is selected or the coefficients are exported.
+static int explicit_from_image(deff_ctx *c)
+{
+    if (c->have_explicit) return DEFF_OK;
+    if (!c->have_matfree) return fail(DEFF_ESTATE, "no system assembled");
+    TRY(ensure_explicit(c));
+    TRY(ensure_scratch(c, sizeof(double) * c->n));
+    double *D = (double *)c->scratch;
+    hipLaunchKernelGGL(k_fill_D_2phase, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->W, c->ampX,
+                       c->ampY, c->nx, c->ny, c->Df, c->Ds, D);
+    hipLaunchKernelGGL(k_assemble_from_D, dim3(grid_for(c->n)), dim3(256), 0, c->stream, D,
+                       (const unsigned int *)nullptr, c->nx, c->ny, c->dx, c->dy, c->CL, c->CR, soa_of(c));
+    HIP_TRY(hipGetLastError());
+    c->have_explicit = true;
+    c->c0_omega = NAN;
+    return DEFF_OK;
+}
+
+// Host -> device in bounded chunks through the scratch buffer.
+static const size_t CHUNK_CELLS = (size_t)1 << 22;   // 4 Mi cells
+
+extern "C" int deff_assemble_from_D(deff_ctx *c, const double *D, const unsigned int *Grid, double CL,
+                                    double CR)
+{
+    if (!c || !D) return fail(DEFF_EINVAL, "NULL argument");
+    TRY(use_device(c));
+    TRY(ensure_explicit(c));
+    TRY(ensure_walls(c));
+    const size_t bytes = sizeof(double) * c->n + (Grid ? sizeof(unsigned int) * c->n : 0);
+    TRY(ensure_scratch(c, bytes));
+    double *dD = (double *)c->scratch;
+    unsigned int *dG = Grid ? (unsigned int *)((char *)c->scratch + sizeof(double) * c->n) : nullptr;
+    HIP_TRY(hipMemcpyAsync(dD, D, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
+    if (Grid) HIP_TRY(hipMemcpyAsync(dG, Grid, sizeof(unsigned int) * c->n, hipMemcpyHostToDevice, c->stream));
+    c->CL = CL; c->CR = CR;
+    hipLaunchKernelGGL(k_assemble_from_D, dim3(grid_for(c->n)), dim3(256), 0, c->stream, dD, dG, c->nx,
+                       c->ny, c->dx, c->dy, CL, CR, soa_of(c));
+    hipLaunchKernelGGL(k_wall_D_from_D, dim3((c->ny + 255) / 256), dim3(256), 0, c->stream, dD, c->nx, c->ny,
+                       c->Dl, c->Dr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_explicit = true; c->c0_omega = NAN; c->have_walls = true;
+    c->have_matfree = false;
+    return DEFF_OK;
+}
+
+extern "C" int deff_set_system(deff_ctx *c, const double *A, const double *b, const double *D, double CL,
+                               double CR)
+{
+    if (!c || !A || !b) return fail(DEFF_EINVAL, "NULL argument");
+    TRY(use_device(c));
+    TRY(ensure_explicit(c));
+    TRY(ensure_scratch(c, sizeof(double) * 5 * CHUNK_CELLS));
+    for (size_t first = 0; first < c->n; first += CHUNK_CELLS) {
+        const size_t cnt = (c->n - first < CHUNK_CELLS) ? c->n - first : CHUNK_CELLS;
+        HIP_TRY(hipMemcpyAsync(c->scratch, A + first * 5, sizeof(double) * 5 * cnt, hipMemcpyHostToDevice,
+                               c->stream));
+        hipLaunchKernelGGL(k_import_aos, dim3(grid_for(cnt)), dim3(256), 0, c->stream,
+                           (const double *)c->scratch, first, cnt, soa_of(c));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(c->b, b, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
+    c->CL = CL; c->CR = CR;
+    c->have_walls = false;
+    if (D) {
+        TRY(ensure_walls(c));
+        // only the first and last column of D are ever read (cuh:1256-1257)
+        for (int i = 0; i < c->ny; ++i) {
+            c->mf_host[i] = D[(size_t)i * c->nx];
+            c->mf_host[c->ny + i] = D[(size_t)(i + 1) * c->nx - 1];
+        }
+        HIP_TRY(hipMemcpyAsync(c->Dl, c->mf_host, sizeof(double) * c->ny, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->Dr, c->mf_host + c->ny, sizeof(double) * c->ny, hipMemcpyHostToDevice,
+                               c->stream));
+        c->have_walls = true;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_explicit = true; c->c0_omega = NAN;
+    c->have_matfree = false;
+    return DEFF_OK;
+}
+
+extern "C" int deff_get_system(deff_ctx *c, double *A, double *b)
+{
+    if (!c || !A || !b) return fail(DEFF_EINVAL, "NULL argument");
+    TRY(use_device(c));
+    if (c->have_explicit) {
+        TRY(ensure_scratch(c, sizeof(double) * 5 * CHUNK_CELLS));
+        for (size_t first = 0; first < c->n; first += CHUNK_CELLS) {
+            const size_t cnt = (c->n - first < CHUNK_CELLS) ? c->n - first : CHUNK_CELLS;
+            hipLaunchKernelGGL(k_export_aos, dim3(grid_for(cnt)), dim3(256), 0, c->stream, (double *)c->scratch,
+                               first, cnt, soa_of(c));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(A + first * 5, c->scratch, sizeof(double) * 5 * cnt, hipMemcpyDeviceToHost,
+                                   c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(b, c->b, sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return DEFF_OK;
+    }
+    if (c->have_matfree) {
+        // expand codes through the tables (what the matrix-free kernel "sees")
+        std::vector<uint8_t> code(c->n);
+        HIP_TRY(hipMemcpyAsync(code.data(), c->code, c->n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < c->ny; ++i)
+            for (int j = 0; j < c->nx; ++j) {
+                const size_t p = (size_t)i * c->nx + j;
+                const int idx = (pos_class(i, c->ny) * 3 + pos_class(j, c->nx)) * LUT_CODES + (code[p] & 31);
+                A[p * 5 + 0] = c->lut_a0[idx];
+                for (int k = 1; k < 5; ++k) A[p * 5 + k] = c->lut_host[k * LUT_PLANE_STRIDE + idx];
+                b[p] = c->lut_host[5 * LUT_PLANE_STRIDE + idx];
+            }
+        return DEFF_OK;
+    }
+    return fail(DEFF_ESTATE, "no system assembled");
+}
+
+// ------------------------------------------------------------ field -------
+
+extern "C" int deff_init_linear(deff_ctx *c, double CL, double CR)
+{
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    TRY(use_device(c));
+    hipLaunchKernelGGL(k_init_linear, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->x[c->cur], c->nx,
+                       c->ny, CL, CR);
+    HIP_TRY(hipGetLastError());
+    c->have_field = true;
+    return DEFF_OK;
+}
+
+extern "C" int deff_set_field(deff_ctx *c, const double *x)
+{
+    if (!c || !x) return fail(DEFF_EINVAL, "NULL argument");
+    TRY(use_device(c));
+    HIP_TRY(hipMemcpyAsync(c->x[c->cur], x, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_field = true;
+    return DEFF_OK;
+}
+
+extern "C" int deff_get_field(deff_ctx *c, double *x)
+{
+    if (!c || !x) return fail(DEFF_EINVAL, "NULL argument");
+    TRY(use_device(c));
+    HIP_TRY(hipMemcpyAsync(x, c->x[c->cur], sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DEFF_OK;
+}
+
+extern "C" int deff_device_field(deff_ctx *c, void **d_x, size_t *pitch)
+{
+    if (!c || !d_x) return fail(DEFF_EINVAL, "NULL argument");
+    *d_x = c->x[c->cur];
+    if (pitch) *pitch = sizeof(double) * c->nx;
+    return DEFF_OK;
+}
+
+extern "C" int deff_synchronize(deff_ctx *c)
+{
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    TRY(use_device(c));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DEFF_OK;
+}
+
+// ----------------------------------------------------------- sweeps -------
+
+struct SweepPlan {
+    int kernel = 0;
+    double omw = 0;
+    int rows = 0, gx = 0, gy = 0, blocks = 0;
+};
+
+static void tile_grid(const deff_ctx *c, int cols_per_block, int rows, SweepPlan *pl)
+{
+    pl->rows = rows;
+    pl->gx = (c->nx + cols_per_block - 1) / cols_per_block;
+    pl->gy = (c->ny + rows - 1) / rows;
+    const unsigned total = (unsigned)pl->gx * (unsigned)pl->gy;
+    pl->blocks = (int)(((total + 7u) / 8u) * 8u);      // see xcd_tile()
+}
+
+// Rows marched per workgroup: enough workgroups to fill 256 CUs several times
+// over, few enough that the halo rows (re-read by two workgroups) stay cheap.
+static int default_rows(const deff_ctx *c, int cols_per_block)
+{
+    const long gx = (c->nx + cols_per_block - 1) / cols_per_block;
+    int rows = 32;
+    while (rows > 4 && gx * ((c->ny + rows - 1) / rows) < 2048) rows >>= 1;
+    return rows;
+}
+
+static int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
+{
+    if (!c->have_field) return fail(DEFF_ESTATE, "no field: call deff_init_linear() or deff_set_field()");
+    TRY(resolve_kernel(c, &pl->kernel));
+    pl->omw = 1.0 - omega;                              // cuh:89 evaluates (1.0 - w) in double
+    if (pl->kernel == DEFF_KERNEL_MATFREE) {
+        TRY(upload_lut(c, omega));
+        const int vec = (c->nx & 1) ? 1 : 2;
+        tile_grid(c, 256 * vec, c->rows_matfree ? c->rows_matfree : default_rows(c, 256 * vec), pl);
+    } else {
+        TRY(explicit_from_image(c));
+        if (c->c0_omega != omega) {
+            hipLaunchKernelGGL(k_make_c0, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->a0, omega, c->c0,
+                               c->n);
+            HIP_TRY(hipGetLastError());
+            c->c0_omega = omega;
+        }
+        if (pl->kernel == DEFF_KERNEL_EXPLICIT)
+            tile_grid(c, 512, c->rows_explicit ? c->rows_explicit : default_rows(c, 512), pl);
+    }
+    return DEFF_OK;
+}
+
+// Enqueue one sweep x[cur] -> x[cur^1] and flip (the reference copies instead, cuh:1281).
+static inline void enqueue_sweep(deff_ctx *c, const SweepPlan &pl)
+{
+    const double *xin = c->x[c->cur];
+    double *xout = c->x[c->cur ^ 1];
+    const CoefConst cf{c->c0, c->aW, c->aE, c->aS, c->aN, c->b};
+    switch (pl.kernel) {
+    case DEFF_KERNEL_SCALAR:
+        hipLaunchKernelGGL(k_sweep_scalar, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, cf,
+                           xin, xout, c->nx, c->n, pl.omw);
+        break;
+    case DEFF_KERNEL_EXPLICIT:
+        hipLaunchKernelGGL(k_sweep_explicit, dim3(pl.blocks), dim3(256), 0, c->stream, cf, xin, xout, c->nx,
+                           c->ny, pl.rows, pl.gx, pl.gy, pl.omw);
+        break;
+    default:
+        if (c->nx & 1)
+            hipLaunchKernelGGL(k_sweep_matfree<1>, dim3(pl.blocks), dim3(256), 0, c->stream, c->lut, c->code,
+                               xin, xout, c->nx, c->ny, pl.rows, pl.gx, pl.gy, pl.omw);
+        else
+            hipLaunchKernelGGL(k_sweep_matfree<2>, dim3(pl.blocks), dim3(256), 0, c->stream, c->lut, c->code,
+                               xin, xout, c->nx, c->ny, pl.rows, pl.gx, pl.gy, pl.omw);
+        break;
+    }
+    c->cur ^= 1;
+}
+
+extern "C" int deff_sweeps(deff_ctx *c, int64_t nsweeps, double omega, float *ms)
+{
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    if (nsweeps < 0) return fail(DEFF_EINVAL, "negative sweep count");
+    TRY(use_device(c));
+    SweepPlan pl;
+    TRY(plan_sweeps(c, omega, &pl));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (int64_t s = 0; s < nsweeps; ++s) enqueue_sweep(c, pl);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    if (ms) HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return DEFF_OK;
+}
+
+// Wall fluxes of the current field -> Deff (cuh:1252-1263), summed on the host
+// in row order like the reference.
+static int flux_now(deff_ctx *c, double *deff_raw, double *MFL, double *MFR)
+{
+    if (!c->have_walls)
+        return fail(DEFF_ESTATE, "wall diffusivities unknown: pass D to deff_set_system() or assemble on the device");
+    hipLaunchKernelGGL(k_wall_flux, dim3((c->ny + 255) / 256), dim3(256), 0, c->stream, c->x[c->cur], c->Dl,
+                       c->Dr, c->nx, c->ny, c->dx, c->CL, c->CR, c->mf);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->mf_host, c->mf, sizeof(double) * 2 * c->ny, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double Q1 = 0, Q2 = 0;
+    for (int j = 0; j < c->ny; ++j) {
+        Q1 += c->mf_host[j];
+        Q2 += c->mf_host[c->ny + j];
+    }
+    const double qAvg = (Q1 + Q2) / (2.0 * c->ny);
+    *deff_raw = qAvg / ((c->CR - c->CL));
+    if (MFL) memcpy(MFL, c->mf_host, sizeof(double) * c->ny);
+    if (MFR) memcpy(MFR, c->mf_host + c->ny, sizeof(double) * c->ny);
+    return DEFF_OK;
+}
+
+extern "C" int deff_flux(deff_ctx *c, double *deff_raw, double *MFL, double *MFR)
+{
+    if (!c || !deff_raw) return fail(DEFF_EINVAL, "NULL argument");
+    if (!c->have_field) return fail(DEFF_ESTATE, "no field");
+    TRY(use_device(c));
+    return flux_now(c, deff_raw, MFL, MFR);
+}
+
+// JacobiGPU's loop, cuh:1232-1290, with the sweeps between two checks enqueued
+// without host round trips.  `iter` counts completed sweeps; the sweep with
+// 0-based index k is followed by a check iff k % check_every == 0 (cuh:1243).
+extern "C" int deff_solve(deff_ctx *c, double omega, double tol, int64_t max_iter, int64_t check_every,
+                          deff_result *out, double *MFL, double *MFR)
+{
+    if (!c || !out) return fail(DEFF_EINVAL, "NULL argument");
+    if (check_every < 1) return fail(DEFF_EINVAL, "check_every must be >= 1");
+    TRY(use_device(c));
+    SweepPlan pl;
+    TRY(plan_sweeps(c, omega, &pl));
+    if (!c->have_walls) return fail(DEFF_ESTATE, "wall diffusivities unknown (needed for Deff)");
+
+    int64_t iter = 0, checks = 0;
+    double deffNew = 1, deffOld = 5, change = 100.0, conv = 0;      // cuh:1171-1173
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    while (iter < max_iter && tol < fabs(change)) {                  // cuh:1232
+        const int64_t next_check = ((iter + check_every - 1) / check_every) * check_every;
+        const bool do_check = next_check < max_iter;
+        const int64_t batch = do_check ? next_check - iter + 1 : max_iter - iter;
+        for (int64_t s = 0; s < batch; ++s) enqueue_sweep(c, pl);
+        HIP_TRY(hipGetLastError());
+        iter += batch;
+        if (do_check) {
+            TRY(flux_now(c, &deffNew, MFL, MFR));
+            change = (deffOld - deffNew) / (deffOld);                // cuh:1265
+            deffOld = deffNew;
+            conv = change;                                           // cuh:1275
+            ++checks;
+        }
+    }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    out->iters = iter;
+    out->checks = checks;
+    out->deff_raw = deffNew;                                         // cuh:1309: value at the last check
+    out->conv = conv;
+    out->loop_ms = ms;
+    return DEFF_OK;
+}

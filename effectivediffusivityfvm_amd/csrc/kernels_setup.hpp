@@ -1,0 +1,184 @@
+// kernels_setup.hpp -- once-per-image device kernels (gfx950): image -> phases,
+// coefficient assembly, layout import/export, initial guess, wall fluxes.
+// None of these is on the per-sweep path; they are written for exactness and
+// coalescing, not for the last percent.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fvm_row.hpp"
+
+namespace deff {
+
+// ---------------------------------------------------------------- image ---
+
+// Synthetic two-phase mask of SURVEY.md 8d (splitmix64 of a per-pixel key).
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void k_synth_mask(uint8_t *__restrict__ pix, int nx, int ny, uint64_t seed, uint64_t img)
+{
+    const size_t n = (size_t)nx * ny;
+    const uint64_t base = seed * 0x100000001B3ull + img * (uint64_t)n;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
+         p += (size_t)gridDim.x * blockDim.x)
+        pix[p] = (splitmix64(base + p) >> 63) ? 255 : 0;
+}
+
+// Pixel of mesh cell (i, j) under nearest-neighbour amplification, cuh:1992-1994.
+__device__ __forceinline__ uint8_t cell_pixel(const uint8_t *pix, int W, int ampX, int ampY,
+                                              int i, int j)
+{
+    return pix[(size_t)(i / ampY) * W + (j / ampX)];
+}
+
+// 2-phase D fill, cuh:1988-2000: pixel < 150 -> fluid.
+__global__ void k_fill_D_2phase(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
+                                int nx, int ny, double DCF, double DCS, double *__restrict__ D)
+{
+    const size_t n = (size_t)nx * ny;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
+         p += (size_t)gridDim.x * blockDim.x) {
+        int i = (int)(p / nx), j = (int)(p % nx);
+        D[p] = (cell_pixel(pix, W, ampX, ampY, i, j) < 150) ? DCF : DCS;
+    }
+}
+
+// Diffusivity of the first and last cell of every row, for the wall fluxes
+// (cuh:1256-1257 read D[j*nx] and D[(j+1)*nx-1]).
+__global__ void k_wall_D_2phase(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
+                                int nx, int ny, double DCF, double DCS,
+                                double *__restrict__ Dl, double *__restrict__ Dr)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ny) return;
+    Dl[i] = (cell_pixel(pix, W, ampX, ampY, i, 0) < 150) ? DCF : DCS;
+    Dr[i] = (cell_pixel(pix, W, ampX, ampY, i, nx - 1) < 150) ? DCF : DCS;
+}
+
+__global__ void k_wall_D_from_D(const double *__restrict__ D, int nx, int ny,
+                                double *__restrict__ Dl, double *__restrict__ Dr)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ny) return;
+    Dl[i] = D[(size_t)i * nx];
+    Dr[i] = D[(size_t)(i + 1) * nx - 1];
+}
+
+// Matrix-free phase code, one byte per cell: bit0 own phase (1 = solid, i.e.
+// pixel >= 150), bit1 W, bit2 E, bit3 S (row+1), bit4 N (row-1) neighbour
+// phases.  Neighbours outside the mesh read the clamped cell; their bits are
+// never used because the lookup tables are selected by position class.
+__global__ void k_phase_codes(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
+                              int nx, int ny, uint8_t *__restrict__ code)
+{
+    const size_t n = (size_t)nx * ny;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
+         p += (size_t)gridDim.x * blockDim.x) {
+        int i = (int)(p / nx), j = (int)(p % nx);
+        int jw = j > 0 ? j - 1 : j, je = j < nx - 1 ? j + 1 : j;
+        int is = i < ny - 1 ? i + 1 : i, in = i > 0 ? i - 1 : i;
+        unsigned c = (cell_pixel(pix, W, ampX, ampY, i, j) >= 150) ? 1u : 0u;
+        c |= (cell_pixel(pix, W, ampX, ampY, i, jw) >= 150) ? 2u : 0u;
+        c |= (cell_pixel(pix, W, ampX, ampY, i, je) >= 150) ? 4u : 0u;
+        c |= (cell_pixel(pix, W, ampX, ampY, is, j) >= 150) ? 8u : 0u;
+        c |= (cell_pixel(pix, W, ampX, ampY, in, j) >= 150) ? 16u : 0u;
+        code[p] = (uint8_t)c;
+    }
+}
+
+// ------------------------------------------------------------- assembly ---
+
+struct CoefSoA {
+    double *a0, *aW, *aE, *aS, *aN, *b;
+};
+
+// General assembly from a per-cell D array (DiscretizeMatrix2D cuh:815-902;
+// with Grid != nullptr, DiscretizeMatrix2D_ImpSolid cuh:715-812: Grid 1 or 2
+// gets the identity row, cuh:750-752).
+__global__ void k_assemble_from_D(const double *__restrict__ D, const unsigned int *__restrict__ Grid,
+                                  int nx, int ny, double dx, double dy, double CL, double CR,
+                                  CoefSoA c)
+{
+    const size_t n = (size_t)nx * ny;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
+         p += (size_t)gridDim.x * blockDim.x) {
+        int i = (int)(p / nx), j = (int)(p % nx);
+        FvmRow r;
+        if (Grid != nullptr && (Grid[p] == 1 || Grid[p] == 2)) {
+            r.a0 = 1; r.aW = 0; r.aE = 0; r.aS = 0; r.aN = 0; r.b = 0;
+        } else {
+            // clamped neighbour reads; values at clamped positions are unused
+            double Dp = D[p];
+            double Dw = D[j > 0 ? p - 1 : p];
+            double De = D[j < nx - 1 ? p + 1 : p];
+            double Ds = D[i < ny - 1 ? p + nx : p];
+            double Dn = D[i > 0 ? p - nx : p];
+            r = fvm_row(Dp, Dw, De, Ds, Dn, pos_class(j, nx), pos_class(i, ny), dx, dy, CL, CR);
+        }
+        c.a0[p] = r.a0; c.aW[p] = r.aW; c.aE[p] = r.aE; c.aS[p] = r.aS; c.aN[p] = r.aN; c.b[p] = r.b;
+    }
+}
+
+// AoS [cells][5] chunk -> SoA planes (import of a host-assembled matrix).
+__global__ void k_import_aos(const double *__restrict__ A, size_t first, size_t count, CoefSoA c)
+{
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < count;
+         q += (size_t)gridDim.x * blockDim.x) {
+        const double *a = A + q * 5;
+        size_t p = first + q;
+        c.a0[p] = a[0]; c.aW[p] = a[1]; c.aE[p] = a[2]; c.aS[p] = a[3]; c.aN[p] = a[4];
+    }
+}
+
+__global__ void k_export_aos(double *__restrict__ A, size_t first, size_t count, CoefSoA c)
+{
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < count;
+         q += (size_t)gridDim.x * blockDim.x) {
+        double *a = A + q * 5;
+        size_t p = first + q;
+        a[0] = c.a0[p]; a[1] = c.aW[p]; a[2] = c.aE[p]; a[3] = c.aS[p]; a[4] = c.aN[p];
+    }
+}
+
+// c0 = w / A0: the reference evaluates w/A[p*5+0] first and multiplies the
+// result by (b - sigma) (cuh:89, C precedence), so hoisting the division out
+// of the sweep keeps every bit.
+__global__ void k_make_c0(const double *__restrict__ a0, double w, double *__restrict__ c0, size_t n)
+{
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
+         p += (size_t)gridDim.x * blockDim.x)
+        c0[p] = w / a0[p];
+}
+
+// ---------------------------------------------------------------- field ---
+
+// Linear ramp, cuh:1955-1959: (double)j/nx*(CR-CL)+CL.
+__global__ void k_init_linear(double *__restrict__ x, int nx, int ny, double CL, double CR)
+{
+    const size_t n = (size_t)nx * ny;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
+         p += (size_t)gridDim.x * blockDim.x) {
+        int j = (int)(p % nx);
+        x[p] = (double)j / nx * (CR - CL) + CL;
+    }
+}
+
+// Wall fluxes of every row, cuh:1256-1257.  The host adds them up in row order
+// (cuh:1258-1259) so Deff has the reference's summation order; the transfer is
+// 16*ny bytes per check instead of the reference's whole field (cuh:1245).
+__global__ void k_wall_flux(const double *__restrict__ x, const double *__restrict__ Dl,
+                            const double *__restrict__ Dr, int nx, int ny, double dx,
+                            double CL, double CR, double *__restrict__ mf)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ny) return;
+    mf[i] = Dl[i] * (x[(size_t)i * nx] - CL) / (dx / 2.0);
+    mf[ny + i] = Dr[i] * (CR - x[(size_t)(i + 1) * nx - 1]) / (dx / 2.0);
+}
+
+}  // namespace deff

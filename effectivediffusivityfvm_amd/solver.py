@@ -1,0 +1,155 @@
+"""Host-side wrapper of one solver context (one GPU, one mesh).
+
+Thin: every method is one call into the C ABI (include/deff_amd.h).  Array
+conventions are the reference's: row-major (ny, nx) fields, A as (n, 5) =
+P, W, E, S(row+1), N(row-1) (Deff2D.cuh:815-902).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import KERNEL_NAMES, DeffError, Result, check
+
+OMEGA_REFERENCE = 2.0 / 3.0     # updateX_SOR, Deff2D.cuh:72
+
+
+class SolveResult:
+    __slots__ = ("iters", "checks", "deff_raw", "conv", "loop_ms", "MFL", "MFR")
+
+    def __repr__(self):
+        return (f"SolveResult(iters={self.iters}, checks={self.checks}, deff_raw={self.deff_raw!r}, "
+                f"conv={self.conv!r}, loop_ms={self.loop_ms:.3f})")
+
+
+class Solver:
+    def __init__(self, nx, ny, device=0, kernel="auto"):
+        self._L = _capi.load()
+        self._ctx = C.c_void_p()
+        self.nx, self.ny = int(nx), int(ny)
+        check(self._L.deff_create(int(device), self.nx, self.ny, C.byref(self._ctx)))
+        if kernel != "auto":
+            self.set_kernel(kernel)
+
+    # -- lifecycle --------------------------------------------------------
+    def close(self):
+        if self._ctx:
+            self._L.deff_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_kernel(self, kernel):
+        k = KERNEL_NAMES[kernel] if isinstance(kernel, str) else int(kernel)
+        check(self._L.deff_set_kernel(self._ctx, k))
+
+    def kernel_in_use(self):
+        k = C.c_int()
+        check(self._L.deff_get_kernel(self._ctx, C.byref(k)))
+        return {v: n for n, v in KERNEL_NAMES.items()}[k.value]
+
+    def set_tuning(self, key, value):
+        check(self._L.deff_set_tuning(self._ctx, key.encode(), int(value)))
+
+    # -- image / assembly -------------------------------------------------
+    def set_image(self, pix, ampX=1, ampY=1):
+        pix = np.ascontiguousarray(pix, dtype=np.uint8)
+        H, W = pix.shape
+        check(self._L.deff_set_image(self._ctx, pix, W, H, ampX, ampY))
+
+    def synth_image(self, seed=12345, img=0):
+        check(self._L.deff_synth_image(self._ctx, seed, img))
+
+    def get_image(self):
+        out = np.empty((self.ny, self.nx), dtype=np.uint8)   # only valid for amp 1
+        check(self._L.deff_get_image(self._ctx, out))
+        return out
+
+    def assemble_2phase(self, Ds, Df, CL, CR):
+        check(self._L.deff_assemble_2phase(self._ctx, Ds, Df, CL, CR))
+
+    def assemble_from_D(self, D, CL, CR, grid=None):
+        D = np.ascontiguousarray(D, dtype=np.float64)
+        g = None
+        if grid is not None:
+            grid = np.ascontiguousarray(grid, dtype=np.uint32)
+            g = grid.ctypes.data_as(C.c_void_p)
+        check(self._L.deff_assemble_from_D(self._ctx, D, g, CL, CR))
+
+    def set_system(self, A, b, D, CL, CR):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        d = None
+        if D is not None:
+            D = np.ascontiguousarray(D, dtype=np.float64)
+            d = D.ctypes.data_as(C.c_void_p)
+        check(self._L.deff_set_system(self._ctx, A, b, d, CL, CR))
+
+    def get_system(self):
+        n = self.nx * self.ny
+        A = np.empty((n, 5), dtype=np.float64)
+        b = np.empty(n, dtype=np.float64)
+        check(self._L.deff_get_system(self._ctx, A, b))
+        return A, b
+
+    # -- field ------------------------------------------------------------
+    def init_linear(self, CL, CR):
+        check(self._L.deff_init_linear(self._ctx, CL, CR))
+
+    def set_field(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.size == self.nx * self.ny
+        check(self._L.deff_set_field(self._ctx, x))
+
+    def get_field(self):
+        x = np.empty((self.ny, self.nx), dtype=np.float64)
+        check(self._L.deff_get_field(self._ctx, x))
+        return x
+
+    # -- solve ------------------------------------------------------------
+    def solve(self, tol, max_iter, omega=OMEGA_REFERENCE, check_every=10000):
+        res = Result()
+        MFL = np.zeros(self.ny)
+        MFR = np.zeros(self.ny)
+        check(self._L.deff_solve(self._ctx, omega, tol, int(max_iter), int(check_every), C.byref(res),
+                                 MFL.ctypes.data_as(C.c_void_p), MFR.ctypes.data_as(C.c_void_p)))
+        out = SolveResult()
+        out.iters, out.checks = res.iters, res.checks
+        out.deff_raw, out.conv, out.loop_ms = res.deff_raw, res.conv, res.loop_ms
+        out.MFL, out.MFR = MFL, MFR
+        return out
+
+    def sweeps(self, n, omega=OMEGA_REFERENCE):
+        ms = C.c_float()
+        check(self._L.deff_sweeps(self._ctx, int(n), omega, C.byref(ms)))
+        return ms.value
+
+    def flux(self):
+        d = C.c_double()
+        MFL = np.zeros(self.ny)
+        MFR = np.zeros(self.ny)
+        check(self._L.deff_flux(self._ctx, C.byref(d), MFL.ctypes.data_as(C.c_void_p),
+                                MFR.ctypes.data_as(C.c_void_p)))
+        return d.value, MFL, MFR
+
+    def device_field_ptr(self):
+        p = C.c_void_p()
+        pitch = C.c_size_t()
+        check(self._L.deff_device_field(self._ctx, C.byref(p), C.byref(pitch)))
+        return p.value, pitch.value
+
+    def synchronize(self):
+        check(self._L.deff_synchronize(self._ctx))
+
+
+__all__ = ["Solver", "SolveResult", "DeffError", "OMEGA_REFERENCE"]

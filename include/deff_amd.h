@@ -1,0 +1,120 @@
+/*
+ * deff_amd.h -- C ABI of the MI355X-native effective-diffusivity hot path.
+ *
+ * One shared library, libdeff_amd.so (HIP, gfx950).  Plain pointers and sizes
+ * only; no C++ or torch types cross this boundary.  The reference has no FFI:
+ * its seam is function-level inside one translation unit, so
+ * each entry point below cites the reference function (Deff2DGPU/Deff2D.cuh,
+ * "cuh:line") whose work it takes over.  A C++ mirror with the reference's
+ * own names and argument lists (DiscretizeMatrix2D, initializeGPU, JacobiGPU,
+ * ...) sits on top of this ABI in
+ * effectivediffusivityfvm_amd/csrc/reference_seam.hpp; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns DEFF_OK (0) or a negative DEFF_E* code and never
+ *     blocks on stdin (the reference calls getchar() on failure, cuh:912-916);
+ *     deff_last_error() gives the message of the calling thread's last failure;
+ *   - a context is bound to one device and one (nx, ny) mesh, owns every device
+ *     buffer and one HIP stream, and is reused across images (the reference
+ *     re-allocates and resets the device per image, cuh:2038, cuh:1015);
+ *   - a context is not thread-safe; use one per host thread / per GPU;
+ *   - host arrays are row-major, cell p = i*nx + j, exactly as in the
+ *     reference; "AoS" coefficient arrays are [n][5] = P,W,E,S(row+1),N(row-1).
+ */
+#ifndef DEFF_AMD_H
+#define DEFF_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEFF_OK            0
+#define DEFF_EINVAL       -1   /* bad argument / call order */
+#define DEFF_EHIP         -2   /* a HIP runtime call failed */
+#define DEFF_ENOMEM       -3   /* device or host allocation failed */
+#define DEFF_ENODEV       -4   /* no usable gfx950 device */
+#define DEFF_ESTATE       -5   /* system / field not set before solve */
+#define DEFF_ECOMM        -6   /* RCCL failure (row-slab mode) */
+
+/* sweep kernel selection, deff_set_kernel() */
+#define DEFF_KERNEL_AUTO       0
+#define DEFF_KERNEL_EXPLICIT   1   /* SoA coefficient streams, 64 B/cell/sweep */
+#define DEFF_KERNEL_SCALAR     2   /* 1 cell/thread, any nx; correctness fallback */
+#define DEFF_KERNEL_MATFREE    3   /* coefficients from the phase code, 17 B/cell/sweep */
+#define DEFF_KERNEL_MATFREE_TB 4   /* matrix-free, several sweeps per HBM pass */
+
+typedef struct deff_ctx deff_ctx;
+
+typedef struct deff_result {
+    int64_t iters;      /* sweeps executed: 10000k+1 or max_iter (cuh:1289, return value) */
+    int64_t checks;     /* convergence checks performed */
+    double  deff_raw;   /* Deff at the LAST CHECK, not normalised by Df (cuh:1309) */
+    double  conv;       /* last signed relative change (cuh:1275) */
+    double  loop_ms;    /* hipEvent time of the sweep loop, same window as cuh:1230-1298 */
+} deff_result;
+
+/* ---- library ---------------------------------------------------------- */
+const char *deff_version(void);
+const char *deff_last_error(void);
+const char *deff_error_string(int code);
+int deff_device_count(int *count);
+
+/* ---- lifecycle: replaces initializeGPU cuh:904-981 / unInitializeGPU cuh:983-1021 */
+int deff_create(int device, int nx, int ny, deff_ctx **out);
+int deff_destroy(deff_ctx *ctx);
+int deff_mesh(const deff_ctx *ctx, int *nx, int *ny, double *dx, double *dy);   /* meshInfo cuh:54-61 */
+int deff_set_kernel(deff_ctx *ctx, int kernel);
+int deff_get_kernel(const deff_ctx *ctx, int *kernel_in_use);
+/* tuning knob (rows marched per workgroup etc.); 0 restores the default */
+int deff_set_tuning(deff_ctx *ctx, const char *key, int value);
+
+/* ---- image -> phases: replaces the mask->D loops cuh:1988-2000 (2-phase),
+ *      cuh:1518-1529 (3-phase) and the synthetic generator of SURVEY.md 8d */
+int deff_set_image(deff_ctx *ctx, const uint8_t *pix, int W, int H, int ampX, int ampY);
+int deff_synth_image(deff_ctx *ctx, uint64_t seed, uint64_t img);   /* generated on the device */
+int deff_get_image(deff_ctx *ctx, uint8_t *pix);                    /* W*H bytes back */
+
+/* ---- assembly: replaces DiscretizeMatrix2D cuh:815-902 (+ WeightedHarmonicMean cuh:347-360) */
+/* native 2-phase path: image already on the device, coefficients never leave it */
+int deff_assemble_2phase(deff_ctx *ctx, double Ds, double Df, double CL, double CR);
+/* drop-in path: caller supplies the per-cell diffusivity D[n] (host); optional
+ * Grid[n] selects DiscretizeMatrix2D_ImpSolid cuh:715-812 semantics (NULL = plain) */
+int deff_assemble_from_D(deff_ctx *ctx, const double *D, const unsigned int *Grid,
+                         double CL, double CR);
+/* host-assembled system as the reference passes it to JacobiGPU (cuh:1163):
+ * A[n*5] AoS, b[n], D[n] (only its first and last column are read, cuh:1256-1257) */
+int deff_set_system(deff_ctx *ctx, const double *A, const double *b, const double *D,
+                    double CL, double CR);
+/* assembled coefficients back in the reference's AoS layout (parity tests, drop-in) */
+int deff_get_system(deff_ctx *ctx, double *A, double *b);
+
+/* ---- field ------------------------------------------------------------- */
+int deff_init_linear(deff_ctx *ctx, double CL, double CR);          /* cuh:1955-1959 */
+int deff_set_field(deff_ctx *ctx, const double *x);                 /* H2D of the guess, cuh:1203 */
+int deff_get_field(deff_ctx *ctx, double *x);                       /* final D2H, cuh:1300 */
+
+/* ---- solve: replaces JacobiGPU cuh:1163-1314 / JacobiGPUPreCond cuh:1024-1160
+ * and the kernels updateX_SOR cuh:69-92 (omega = 2/3) / updateX_V1 cuh:96-118 (omega = 1).
+ * Stopping rule exactly as cuh:1232-1290: check when iter % check_every == 0
+ * (including iter 0), deffOld seeded with 5, stop when |change| <= tol or
+ * iter == max_iter.  MFL/MFR (ny doubles each, may be NULL) receive the wall
+ * fluxes of the last check (cuh:1256-1257). */
+int deff_solve(deff_ctx *ctx, double omega, double tol, int64_t max_iter, int64_t check_every,
+               deff_result *out, double *MFL, double *MFR);
+/* building blocks, also used by bench.py: n sweeps without a check (ms = hipEvent
+ * time on the context's stream), and one flux / Deff evaluation (cuh:1252-1263) */
+int deff_sweeps(deff_ctx *ctx, int64_t n, double omega, float *ms);
+int deff_flux(deff_ctx *ctx, double *deff_raw, double *MFL, double *MFR);
+
+/* raw device pointers for zero-copy interop (torch tensors, RCCL): current field,
+ * and the byte pitch between rows (nx*8: rows are dense) */
+int deff_device_field(deff_ctx *ctx, void **d_x, size_t *row_pitch_bytes);
+int deff_synchronize(deff_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEFF_AMD_H */

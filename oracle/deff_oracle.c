@@ -1,0 +1,303 @@
+/*
+ * deff_oracle.c -- CPU restatement of the reference's hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the reported CPU baseline.
+ * The shipped solver (effectivediffusivityfvm_amd/csrc) never links or calls it.
+ *
+ * What it restates (paths relative to /root/reference/Deff2DGPU, "cuh" =
+ * Deff2D.cuh): the 2-phase mask->D fill, the linear initial guess, the
+ * weighted harmonic mean, the 5-point FVM assembly (plain and "impermeable
+ * solid" variants), the two Jacobi kernels, the boundary-flux / Deff
+ * evaluation and the host stopping rule of JacobiGPU.  Every function cites
+ * the lines it follows.  The arithmetic is written in the reference's own
+ * expression order so that, compiled with -ffp-contract=off (see Makefile),
+ * each double is produced by the same IEEE-754 operation sequence as a
+ * non-contracted build of the reference.
+ *
+ * Parity pinning: the reference cannot be built in this image (it needs
+ * cuda_runtime.h / nvcc launch syntax; no stand-ins are written).  The oracle
+ * is pinned against (i) the analytic known-answer cases of the reference's
+ * own documentation (doc section 5.3) and (ii) the reference outputs recorded
+ * by the survey stage in SURVEY.md section 6 / 8c and BASELINE.md section 2
+ * (110 001 sweeps, Deff 0.18286248993335813 on 00000.jpg; first-check Deff on
+ * the synthetic masks; sweep counts of the analytic table).  See
+ * tests/test_oracle_golden.py.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------- inputs */
+
+/* Synthetic two-phase mask, SURVEY.md section 8d: splitmix64 of a per-pixel
+ * key; pixel 255 (solid, >=150) when the top bit is set, else 0 (fluid). */
+static uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+void oracle_synth_mask(uint8_t *pix, int nx, int ny, uint64_t seed, uint64_t img)
+{
+    const uint64_t base = seed * 0x100000001B3ull + img * (uint64_t)nx * (uint64_t)ny;
+    for (int i = 0; i < ny; i++)
+        for (int j = 0; j < nx; j++) {
+            uint64_t u = splitmix64(base + (uint64_t)i * (uint64_t)nx + (uint64_t)j);
+            pix[(size_t)i * nx + j] = (u >> 63) ? 255 : 0;
+        }
+}
+
+/* cuh:383-408 calcPorosity: fraction of pixels < 150, accumulated as
+ * repeated += 1.0/total in row-major order. */
+double oracle_porosity(const uint8_t *pix, int W, int H)
+{
+    double total = (double)H * W;
+    double porosity = 0;
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++)
+            if (pix[(size_t)i * W + j] < 150)
+                porosity += 1.0 / total;
+    return porosity;
+}
+
+/* cuh:1988-2000 (BatchSim) / cuh:1773-1785 (SingleSim): nearest-neighbour
+ * mesh amplification, pixel < 150 -> fluid. */
+void oracle_fill_D_2phase(const uint8_t *pix, int W, int H, int ampX, int ampY,
+                          double DCF, double DCS, double *D)
+{
+    const int nx = W * ampX, ny = H * ampY;
+    for (int i = 0; i < ny; i++)
+        for (int j = 0; j < nx; j++) {
+            int r = i / ampY, c = j / ampX;
+            D[(size_t)i * nx + j] = (pix[(size_t)r * W + c] < 150) ? DCF : DCS;
+        }
+}
+
+/* cuh:1518-1529 (SingleSim3Phase) / cuh:2286-2297: three-phase fill,
+ * > 200 solid, < 50 gas, otherwise fluid. */
+void oracle_fill_D_3phase(const uint8_t *pix, int W, int H, int ampX, int ampY,
+                          double DCF, double DCS, double DCG, double *D)
+{
+    const int nx = W * ampX, ny = H * ampY;
+    for (int i = 0; i < ny; i++)
+        for (int j = 0; j < nx; j++) {
+            int r = i / ampY, c = j / ampX;
+            uint8_t v = pix[(size_t)r * W + c];
+            D[(size_t)i * nx + j] = (v > 200) ? DCS : (v < 50) ? DCG : DCF;
+        }
+}
+
+/* cuh:1955-1959 / cuh:1730-1734: linear ramp between the two walls. */
+void oracle_linear_guess(double *x, int nx, int ny, double CL, double CR)
+{
+    for (int i = 0; i < ny; i++)
+        for (int j = 0; j < nx; j++)
+            x[(size_t)i * nx + j] = (double)j / nx * (CR - CL) + CL;
+}
+
+/* -------------------------------------------------------------- assembly */
+
+/* cuh:347-360 WeightedHarmonicMean. x==0 gives w/0=+inf and H=0 by IEEE. */
+double oracle_whm(double w1, double w2, double x1, double x2)
+{
+    return (w1 + w2) / (w1 / x1 + w2 / x2);
+}
+
+/* One row of the matrix, shared by the two assembly variants.
+ * cuh:842-897 (and the identical body cuh:754-806 of the ImpSolid variant).
+ * A row is [P, W, E, S(row+1), N(row-1)]. */
+static void assemble_cell(const double *D, double *A, double *b, int nx, int ny,
+                          double dx, double dy, double CL, double CR, int i, int j)
+{
+    const size_t p = (size_t)i * nx + j;
+    double *a = A + p * 5;
+    double dxw, dxe, dys, dyn, kw, ke, ks, kn;
+
+    if (j == 0) {                                   /* cuh:849-856 */
+        dxe = dx;
+        ke = oracle_whm(dxe / 2, dxe / 2, D[p], D[p + 1]);
+        dxw = dx / 2;
+        kw = D[p];
+        a[2] = -ke * dy / dxe;
+        a[0] += (ke * dy / dxe + kw * dy / dxw);
+        b[p] += CL * kw * dy / dxw;
+    } else if (j == nx - 1) {                       /* cuh:857-864 */
+        dxw = dx;
+        kw = oracle_whm(dxw / 2, dxw / 2, D[p], D[p - 1]);
+        dxe = dx / 2;
+        ke = D[p];
+        a[1] = -kw * dy / dxw;
+        a[0] += (ke * dy / dxe + kw * dy / dxw);
+        b[p] += CR * ke * dy / dxe;
+    } else {                                        /* cuh:865-873 */
+        dxw = dx;
+        kw = oracle_whm(dxw / 2, dxw / 2, D[p], D[p - 1]);
+        dxe = dx;
+        ke = oracle_whm(dxe / 2, dxe / 2, D[p], D[p + 1]);
+        a[1] = -kw * dy / dxw;
+        a[2] = -ke * dy / dxe;
+        a[0] += (ke * dy / dxe + kw * dy / dxw);
+    }
+    if (i == 0) {                                   /* cuh:875-881 */
+        dys = dy;
+        ks = oracle_whm(dys / 2, dys / 2, D[p + nx], D[p]);
+        a[3] = -ks * dx / dys;
+        a[0] += (ks * dx / dys);
+    } else if (i == ny - 1) {                       /* cuh:882-888 */
+        dyn = dy;
+        kn = oracle_whm(dyn / 2, dyn / 2, D[p], D[p - nx]);
+        a[4] = -kn * dx / dyn;
+        a[0] += kn * dx / dyn;
+    } else {                                        /* cuh:889-897 */
+        dyn = dy;
+        kn = oracle_whm(dyn / 2, dyn / 2, D[p], D[p - nx]);
+        dys = dy;
+        ks = oracle_whm(dys / 2, dys / 2, D[p + nx], D[p]);
+        a[3] = -ks * dx / dys;
+        a[4] = -kn * dx / dyn;
+        a[0] += (kn * dx / dyn + ks * dx / dys);
+    }
+}
+
+/* cuh:815-902 DiscretizeMatrix2D.  dx = 1/nx, dy = 1/ny are passed in as the
+ * reference passes meshInfo (cuh:1910-1911). */
+void oracle_discretize_2d(const double *D, double *A, double *b, int nx, int ny,
+                          double dx, double dy, double CL, double CR)
+{
+    for (int i = 0; i < ny; i++)
+        for (int j = 0; j < nx; j++) {
+            const size_t p = (size_t)i * nx + j;
+            b[p] = 0;
+            for (int k = 0; k < 5; k++) A[p * 5 + k] = 0;
+            assemble_cell(D, A, b, nx, ny, dx, dy, CL, CR, i, j);
+        }
+}
+
+/* cuh:715-812 DiscretizeMatrix2D_ImpSolid: Grid 1 (solid) or 2
+ * (non-participating) gets the identity row A0=1, b=0 (cuh:750-752). */
+void oracle_discretize_2d_impsolid(const double *D, double *A, double *b, int nx, int ny,
+                                   double dx, double dy, double CL, double CR,
+                                   const unsigned int *Grid)
+{
+    for (int i = 0; i < ny; i++)
+        for (int j = 0; j < nx; j++) {
+            const size_t p = (size_t)i * nx + j;
+            b[p] = 0;
+            for (int k = 0; k < 5; k++) A[p * 5 + k] = 0;
+            if (Grid[p] == 1 || Grid[p] == 2) {
+                A[p * 5 + 0] = 1;
+                b[p] = 0;
+            } else {
+                assemble_cell(D, A, b, nx, ny, dx, dy, CL, CR, i, j);
+            }
+        }
+}
+
+/* ----------------------------------------------------------------- sweeps */
+
+/* cuh:69-92 updateX_SOR: weighted Jacobi, w = 2/3 literal (cuh:72).  The
+ * non-zero guard both skips absent links and keeps edge cells from reading
+ * outside the field.  omega is a parameter here so the same restatement
+ * serves the omega sweep tests; pass 2.0/3.0 for the reference kernel. */
+void oracle_sweep_sor(const double *A, const double *x, const double *b, double *xNew,
+                      int nx, long n, double w)
+{
+    for (long p = 0; p < n; p++) {
+        const double *a = A + p * 5;
+        double sigma = 0;
+        if (a[1] != 0) sigma += a[1] * x[p - 1];
+        if (a[2] != 0) sigma += a[2] * x[p + 1];
+        if (a[3] != 0) sigma += a[3] * x[p + nx];
+        if (a[4] != 0) sigma += a[4] * x[p - nx];
+        xNew[p] = (1.0 - w) * x[p] + w / a[0] * (b[p] - sigma);
+    }
+}
+
+/* cuh:96-118 updateX_V1: plain Jacobi. */
+void oracle_sweep_v1(const double *A, const double *x, const double *b, double *xNew,
+                     int nx, long n)
+{
+    for (long p = 0; p < n; p++) {
+        const double *a = A + p * 5;
+        double sigma = 0;
+        if (a[1] != 0) sigma += a[1] * x[p - 1];
+        if (a[2] != 0) sigma += a[2] * x[p + 1];
+        if (a[3] != 0) sigma += a[3] * x[p + nx];
+        if (a[4] != 0) sigma += a[4] * x[p - nx];
+        xNew[p] = 1 / a[0] * (b[p] - sigma);
+    }
+}
+
+/* Run `sweeps` sweeps with pointer swap; the result is left in x (copied back
+ * if it ended in tmp).  kernel 0 = updateX_SOR(w), 1 = updateX_V1. */
+void oracle_sweeps(const double *A, const double *b, double *x, double *tmp,
+                   int nx, int ny, long sweeps, int kernel, double w)
+{
+    const long n = (long)nx * ny;
+    double *cur = x, *nxt = tmp;
+    for (long s = 0; s < sweeps; s++) {
+        if (kernel == 1) oracle_sweep_v1(A, cur, b, nxt, nx, n);
+        else             oracle_sweep_sor(A, cur, b, nxt, nx, n, w);
+        double *t = cur; cur = nxt; nxt = t;
+    }
+    if (cur != x) memcpy(x, cur, sizeof(double) * (size_t)n);
+}
+
+/* ------------------------------------------------------------ Deff / loop */
+
+/* cuh:1252-1263: wall fluxes row by row (ascending), Deff from their mean.
+ * Returns deffNew (un-normalised); MFL/MFR receive the per-row fluxes. */
+double oracle_flux_deff(const double *x, const double *D, int nx, int ny, double dx,
+                        double CL, double CR, double *MFL, double *MFR)
+{
+    double Q1 = 0, Q2 = 0;
+    for (int j = 0; j < ny; j++) {
+        MFL[j] = D[(size_t)j * nx] * (x[(size_t)j * nx] - CL) / (dx / 2.0);
+        MFR[j] = D[(size_t)(j + 1) * nx - 1] * (CR - x[(size_t)(j + 1) * nx - 1]) / (dx / 2.0);
+        Q1 += MFL[j];
+        Q2 += MFR[j];
+    }
+    double qAvg = (Q1 + Q2) / (2.0 * ny);
+    return qAvg / ((CR - CL));
+}
+
+/* cuh:1163-1314 JacobiGPU (and cuh:1024-1160 JacobiGPUPreCond, which runs the
+ * same loop): x is initial guess in, final field out.  Checks happen when
+ * iter % check_every == 0 including iter 0, deffOld starts at the literal 5,
+ * change = (old-new)/old compared through fabs against tol; a NaN change ends
+ * the loop.  deff_out is the value at the LAST CHECK (not recomputed from the
+ * final field), conv_out the last signed change.  Returns the sweep count. */
+long oracle_jacobi(const double *A, const double *b, double *x, double *tmp,
+                   int nx, int ny, double CL, double CR, double tol, long max_iter,
+                   long check_every, const double *D, double *MFL, double *MFR,
+                   int kernel, double w, double *deff_out, double *conv_out)
+{
+    const long n = (long)nx * ny;
+    const double dx = 1.0 / nx;
+    long iter = 0;
+    double deffNew = 1, deffOld = 5, change = 100.0, conv = 0;
+    double *cur = tmp, *nxt = x;   /* reference: kernel reads d_temp_x, writes d_x */
+    memcpy(tmp, x, sizeof(double) * (size_t)n);          /* cuh:1190-1193 */
+    while (iter < max_iter && tol < fabs(change)) {      /* cuh:1232 */
+        if (kernel == 1) oracle_sweep_v1(A, cur, b, nxt, nx, n);
+        else             oracle_sweep_sor(A, cur, b, nxt, nx, n, w);
+        if (iter % check_every == 0) {                   /* cuh:1243 */
+            deffNew = oracle_flux_deff(nxt, D, nx, ny, dx, CL, CR, MFL, MFR);
+            change = (deffOld - deffNew) / (deffOld);    /* cuh:1265 */
+            deffOld = deffNew;
+            conv = change;                               /* cuh:1275 */
+        }
+        double *t = cur; cur = nxt; nxt = t;             /* cuh:1281 copy-as-swap */
+        iter++;
+    }
+    /* after the swap `cur` holds the newest field (the reference's d_x_vec) */
+    if (iter > 0 && cur != x) memcpy(x, cur, sizeof(double) * (size_t)n);
+    *deff_out = deffNew;                                 /* cuh:1309 */
+    *conv_out = conv;
+    return iter;
+}

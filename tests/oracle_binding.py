@@ -1,0 +1,152 @@
+"""ctypes binding of oracle/libdeff_oracle.so (test infrastructure only).
+
+The oracle is the CPU restatement of the reference hot path; see the header of
+oracle/deff_oracle.c.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB = None
+_LIBS = {}
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def lib(flavour=None):
+    """flavour None = the parity oracle (-ffp-contract=off); "fma" = the
+    contraction-allowed build used only for golden pinning."""
+    global _LIB
+    if flavour is None and _LIB is not None:
+        return _LIB
+    if flavour in _LIBS:
+        return _LIBS[flavour]
+    name = "libdeff_oracle.so" if flavour is None else f"libdeff_oracle_{flavour}.so"
+    path = os.path.join(ORACLE_DIR, name)
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    L.oracle_synth_mask.argtypes = [_u8p, C.c_int, C.c_int, C.c_uint64, C.c_uint64]
+    L.oracle_synth_mask.restype = None
+    L.oracle_porosity.argtypes = [_u8p, C.c_int, C.c_int]
+    L.oracle_porosity.restype = C.c_double
+    L.oracle_fill_D_2phase.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_double, C.c_double, _dp]
+    L.oracle_fill_D_2phase.restype = None
+    L.oracle_fill_D_3phase.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_double, C.c_double, C.c_double, _dp]
+    L.oracle_fill_D_3phase.restype = None
+    L.oracle_linear_guess.argtypes = [_dp, C.c_int, C.c_int, C.c_double, C.c_double]
+    L.oracle_linear_guess.restype = None
+    L.oracle_whm.argtypes = [C.c_double] * 4
+    L.oracle_whm.restype = C.c_double
+    L.oracle_discretize_2d.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double,
+                                       C.c_double, C.c_double]
+    L.oracle_discretize_2d.restype = None
+    L.oracle_discretize_2d_impsolid.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_double,
+                                                C.c_double, C.c_double, C.c_double, _u32p]
+    L.oracle_discretize_2d_impsolid.restype = None
+    L.oracle_sweeps.argtypes = [_dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_long, C.c_int, C.c_double]
+    L.oracle_sweeps.restype = None
+    L.oracle_flux_deff.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                   _dp, _dp]
+    L.oracle_flux_deff.restype = C.c_double
+    L.oracle_jacobi.argtypes = [_dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double,
+                                C.c_double, C.c_long, C.c_long, _dp, _dp, _dp, C.c_int, C.c_double,
+                                C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.oracle_jacobi.restype = C.c_long
+    if flavour is None:
+        _LIB = L
+    _LIBS[flavour] = L
+    return L
+
+
+OMEGA_REF = 2.0 / 3.0   # cuh:72
+
+
+def synth_mask(nx, ny, seed=12345, img=0):
+    pix = np.empty((ny, nx), dtype=np.uint8)
+    lib().oracle_synth_mask(pix, nx, ny, seed, img)
+    return pix
+
+
+def porosity(pix):
+    H, W = pix.shape
+    return lib().oracle_porosity(np.ascontiguousarray(pix), W, H)
+
+
+def fill_D_2phase(pix, DCF, DCS, ampX=1, ampY=1):
+    H, W = pix.shape
+    D = np.empty((H * ampY, W * ampX), dtype=np.float64)
+    lib().oracle_fill_D_2phase(np.ascontiguousarray(pix), W, H, ampX, ampY, DCF, DCS, D)
+    return D
+
+
+def fill_D_3phase(pix, DCF, DCS, DCG, ampX=1, ampY=1):
+    H, W = pix.shape
+    D = np.empty((H * ampY, W * ampX), dtype=np.float64)
+    lib().oracle_fill_D_3phase(np.ascontiguousarray(pix), W, H, ampX, ampY, DCF, DCS, DCG, D)
+    return D
+
+
+def linear_guess(nx, ny, CL, CR):
+    x = np.empty((ny, nx), dtype=np.float64)
+    lib().oracle_linear_guess(x, nx, ny, CL, CR)
+    return x
+
+
+def discretize(D, CL, CR, grid=None):
+    ny, nx = D.shape
+    A = np.empty((ny * nx, 5), dtype=np.float64)
+    b = np.empty(ny * nx, dtype=np.float64)
+    D = np.ascontiguousarray(D)
+    if grid is None:
+        lib().oracle_discretize_2d(D, A, b, nx, ny, 1.0 / nx, 1.0 / ny, CL, CR)
+    else:
+        g = np.ascontiguousarray(grid, dtype=np.uint32)
+        lib().oracle_discretize_2d_impsolid(D, A, b, nx, ny, 1.0 / nx, 1.0 / ny, CL, CR, g)
+    return A, b
+
+
+def sweeps(A, b, x, nsweeps, kernel=0, omega=OMEGA_REF):
+    ny, nx = x.shape
+    x = np.array(x, dtype=np.float64, order="C", copy=True)
+    tmp = np.empty_like(x)
+    lib().oracle_sweeps(A, b, x, tmp, nx, ny, nsweeps, kernel, omega)
+    return x
+
+
+def flux_deff(x, D, CL, CR):
+    ny, nx = x.shape
+    MFL = np.empty(ny)
+    MFR = np.empty(ny)
+    d = lib().oracle_flux_deff(np.ascontiguousarray(x), np.ascontiguousarray(D), nx, ny, 1.0 / nx,
+                               CL, CR, MFL, MFR)
+    return d, MFL, MFR
+
+
+def jacobi(A, b, x0, D, CL, CR, tol, max_iter, check_every=10000, kernel=0, omega=OMEGA_REF,
+           flavour=None):
+    """Returns (iters, deff_raw, conv, field, MFL, MFR)."""
+    ny, nx = x0.shape
+    x = np.array(x0, dtype=np.float64, order="C", copy=True)
+    tmp = np.empty_like(x)
+    MFL = np.zeros(ny)
+    MFR = np.zeros(ny)
+    deff = C.c_double(0)
+    conv = C.c_double(0)
+    it = lib(flavour).oracle_jacobi(A, b, x, tmp, nx, ny, CL, CR, tol, int(max_iter), int(check_every),
+                             np.ascontiguousarray(D), MFL, MFR, kernel, omega,
+                             C.byref(deff), C.byref(conv))
+    return it, deff.value, conv.value, x, MFL, MFR

@@ -1,0 +1,329 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the
+committed golden vectors.  Run on the GPU box: python -m pytest tests -m gpu.
+
+Bars (north_star): concentration field <= 1e-6 relative L2 at the same
+iteration count, Deff <= 1e-8 relative.  The library is built with
+-ffp-contract=off and follows the reference's operation order, so in fact
+every comparison below is also asserted bit-exact against the oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIELD_TOL = 1e-6     # relative L2, north_star
+DEFF_TOL = 1e-8      # relative, north_star
+OMEGA = 2.0 / 3.0
+KERNELS = ["scalar", "explicit", "matfree"]
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import effectivediffusivityfvm_amd as p
+    return p
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def assert_field(got, want):
+    assert rel_l2(got, want) <= FIELD_TOL
+    assert np.array_equal(got, want), f"not bit-exact: rel L2 {rel_l2(got, want):.3e}"
+
+
+def rand_mask(rng, nx, ny, p=0.5):
+    return np.where(rng.random((ny, nx)) < p, 0, 255).astype(np.uint8)
+
+
+# ------------------------------------------------------------------ assembly
+
+@pytest.mark.parametrize("name", ["s8x8", "s16x12", "s33x17"])
+def test_assembly_matches_golden_and_oracle(pkg, oracle, small_cases, name):
+    pix = small_cases[name + "_pix"]
+    Ds, Df, CL, CR = small_cases[name + "_par"]
+    ny, nx = pix.shape
+    Agold, bgold = small_cases[name + "_A"], small_cases[name + "_b"]
+    with pkg.Solver(nx, ny) as s:
+        # native path: pixels -> phase codes + lookup tables (what the matrix-free kernel sees)
+        s.set_image(pix)
+        s.assemble_2phase(Ds, Df, CL, CR)
+        A, b = s.get_system()
+        assert np.array_equal(A, Agold) and np.array_equal(b, bgold)
+        # native path, explicit SoA planes built on the device from the pixels
+        s.set_kernel("explicit")
+        s.init_linear(CL, CR)
+        s.sweeps(0)
+        A, b = s.get_system()
+        assert np.array_equal(A, Agold) and np.array_equal(b, bgold)
+    with pkg.Solver(nx, ny) as s:
+        # drop-in path: DiscretizeMatrix2D(D) on the device
+        D = oracle.fill_D_2phase(pix, Df, Ds)
+        s.assemble_from_D(D, CL, CR)
+        A, b = s.get_system()
+        assert np.array_equal(A, Agold) and np.array_equal(b, bgold)
+        # DiscretizeMatrix2D_ImpSolid
+        s.assemble_from_D(oracle.fill_D_2phase(pix, Df, 0.0), CL, CR, grid=small_cases[name + "_grid"])
+        A, b = s.get_system()
+        assert np.array_equal(A, small_cases[name + "_Aimp"]) and np.array_equal(b, small_cases[name + "_bimp"])
+        # host-assembled system round trip (AoS -> SoA -> AoS)
+        s.set_system(Agold, bgold, D, CL, CR)
+        A, b = s.get_system()
+        assert np.array_equal(A, Agold) and np.array_equal(b, bgold)
+
+
+def test_assembly_mesh_amplification(pkg, oracle):
+    rng = np.random.default_rng(3)
+    pix = rand_mask(rng, 7, 5)
+    for ampX, ampY in [(2, 3), (1, 2), (4, 1)]:
+        nx, ny = 7 * ampX, 5 * ampY
+        D = oracle.fill_D_2phase(pix, 1.0, 1e-3, ampX, ampY)
+        Aor, bor = oracle.discretize(D, 0.0, 1.0)
+        with pkg.Solver(nx, ny) as s:
+            s.set_image(pix, ampX, ampY)
+            s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            A, b = s.get_system()
+            assert np.array_equal(A, Aor) and np.array_equal(b, bor)
+
+
+def test_synth_generator_matches_oracle(pkg, oracle):
+    for (nx, ny, img) in [(64, 48, 0), (130, 70, 3)]:
+        with pkg.Solver(nx, ny) as s:
+            s.synth_image(12345, img)
+            assert np.array_equal(s.get_image(), oracle.synth_mask(nx, ny, 12345, img))
+
+
+# -------------------------------------------------------------------- sweeps
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("name", ["s8x8", "s16x12", "s33x17"])
+def test_sweeps_match_golden(pkg, oracle, small_cases, name, kernel):
+    pix = small_cases[name + "_pix"]
+    Ds, Df, CL, CR = small_cases[name + "_par"]
+    ny, nx = pix.shape
+    with pkg.Solver(nx, ny, kernel=kernel) as s:
+        s.set_image(pix)
+        s.assemble_2phase(Ds, Df, CL, CR)
+        for omega, tag in [(OMEGA, "sor"), (1.0, "v1_")]:
+            s.init_linear(CL, CR)
+            done = 0
+            for k in (1, 2, 100):
+                s.sweeps(k - done, omega)
+                done = k
+                assert_field(s.get_field(), small_cases[f"{name}_{tag}{k}"])
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("shape", [(2, 2), (3, 5), (130, 70), (514, 6), (1030, 37), (600, 300)])
+def test_sweeps_ragged_shapes_vs_oracle(pkg, oracle, shape, kernel):
+    nx, ny = shape
+    rng = np.random.default_rng(nx * 1000 + ny)
+    pix = rand_mask(rng, nx, ny, 0.6)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-3)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    x0 = rng.random((ny, nx))
+    want = oracle.sweeps(A, b, x0, 7)
+    with pkg.Solver(nx, ny, kernel=kernel) as s:
+        s.set_image(pix)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.set_field(x0)
+        s.sweeps(7)
+        assert_field(s.get_field(), want)
+        d, MFL, MFR = s.flux()
+        dor, MFLo, MFRo = oracle.flux_deff(want, D, 0.0, 1.0)
+        assert d == dor and np.array_equal(MFL, MFLo) and np.array_equal(MFR, MFRo)
+
+
+def test_host_assembled_system_drop_in(pkg, oracle):
+    """The reference's own arrays (A AoS, b, D) go in unchanged: set_system + solve."""
+    rng = np.random.default_rng(11)
+    nx, ny = 96, 64
+    pix = rand_mask(rng, nx, ny)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-2)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    x0 = oracle.linear_guess(nx, ny, 0.0, 1.0)
+    it, deff, conv, x, MFL, MFR = oracle.jacobi(A, b, x0, D, 0.0, 1.0, 1e-4, 40000, check_every=1000)
+    for kernel in ("explicit", "scalar"):
+        with pkg.Solver(nx, ny, kernel=kernel) as s:
+            s.set_system(A, b, D, 0.0, 1.0)
+            s.set_field(x0)
+            r = s.solve(1e-4, 40000, check_every=1000)
+            assert r.iters == it and r.deff_raw == deff and r.conv == conv
+            assert_field(s.get_field(), x)
+            assert np.array_equal(r.MFL, MFL) and np.array_equal(r.MFR, MFR)
+
+
+def test_impermeable_solid_system(pkg, oracle, small_cases):
+    """3-phase style rows (identity rows for Grid 1/2, Ds = 0 links) through the explicit kernel."""
+    name = "s33x17"
+    pix = small_cases[name + "_pix"]
+    Ds, Df, CL, CR = small_cases[name + "_par"]
+    ny, nx = pix.shape
+    A, b = small_cases[name + "_Aimp"], small_cases[name + "_bimp"]
+    x0 = oracle.linear_guess(nx, ny, CL, CR)
+    with np.errstate(all="ignore"):
+        want = oracle.sweeps(A, b, x0, 50)
+    D0 = oracle.fill_D_2phase(pix, Df, 0.0)
+    for kernel in ("explicit", "scalar"):
+        with pkg.Solver(nx, ny, kernel=kernel) as s:
+            s.assemble_from_D(D0, CL, CR, grid=small_cases[name + "_grid"])
+            s.set_field(x0)
+            s.sweeps(50)
+            assert_field(s.get_field(), want)
+
+
+# --------------------------------------------------------------- end to end
+
+def test_img00000_config1_end_to_end(pkg, oracle, recorded, img00000):
+    """Config #1 (00000.jpg, Ds 1e-3, tol 1e-6): same 110 001 sweeps, Deff within
+    1e-8 of both recorded reference values, field within 1e-6 rel L2 of the golden field."""
+    rec = recorded["img00000_2phase_batch"]
+    from conftest import GOLDEN
+    gold = np.load(os.path.join(GOLDEN, "img00000_field.npy"))
+    for kernel in KERNELS:
+        with pkg.Solver(128, 128, kernel=kernel) as s:
+            s.set_image(img00000)
+            s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            s.init_linear(0.0, 1.0)
+            r = s.solve(1e-6, 500000)
+            assert r.iters == rec["iters"]
+            deff = r.deff_raw / 1.0                     # normalisation cuh:2017
+            for key in ("deff_build_a", "deff_build_b"):
+                assert abs(deff - rec[key]) / rec[key] <= DEFF_TOL
+            assert deff == rec["deff_build_b"] or deff == rec["deff_build_a"]
+            assert_field(s.get_field(), gold)
+            assert r.checks == 12
+
+
+@pytest.mark.parametrize("max_iter,check_every,tol", [(1, 10000, 1e-6), (5, 10000, 1e-6), (10001, 10000, 1e-6),
+                                                      (10000, 10000, 1e-6), (25, 7, 1e-12), (8, 7, 1e-12),
+                                                      (0, 10000, 1e-6), (300, 10, 1e-2)])
+def test_stopping_rule_edges(pkg, oracle, max_iter, check_every, tol):
+    rng = np.random.default_rng(5)
+    nx, ny = 40, 24
+    pix = rand_mask(rng, nx, ny)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-1)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    x0 = oracle.linear_guess(nx, ny, 0.0, 1.0)
+    it, deff, conv, x, _, _ = oracle.jacobi(A, b, x0, D, 0.0, 1.0, tol, max_iter, check_every=check_every)
+    with pkg.Solver(nx, ny) as s:
+        s.set_image(pix)
+        s.assemble_2phase(1e-1, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        r = s.solve(tol, max_iter, check_every=check_every)
+        assert (r.iters, r.deff_raw, r.conv) == (it, deff, conv)
+        if max_iter > 0:
+            assert_field(s.get_field(), x)
+
+
+def test_two_phase_Ds0_nan_semantics(pkg, oracle, img00000):
+    """Reference behaviour: Ds = 0 makes A0 = 0 cells, Deff = NaN, loop exits after 1 sweep."""
+    for kernel in KERNELS:
+        with pkg.Solver(128, 128, kernel=kernel) as s:
+            s.set_image(img00000)
+            s.assemble_2phase(0.0, 1.0, 0.0, 1.0)
+            s.init_linear(0.0, 1.0)
+            r = s.solve(1e-6, 500000)
+            assert r.iters == 1 and np.isnan(r.deff_raw)
+
+
+def test_warm_start_continuation(pkg, oracle, img00000):
+    """x is in/out (cuh:1163): a second solve starts from the first one's field,
+    which is what the DCF/DCG continuation ramps rely on (cuh:1759-1817)."""
+    D1 = oracle.fill_D_2phase(img00000, 100.0, 1e-3)
+    A1, b1 = oracle.discretize(D1, 0.0, 1.0)
+    x0 = oracle.linear_guess(128, 128, 0.0, 1.0)
+    it1, d1, c1, x1, _, _ = oracle.jacobi(A1, b1, x0, D1, 0.0, 1.0, 1e-3, 30000)
+    D2 = oracle.fill_D_2phase(img00000, 10000.0, 1e-3)
+    A2, b2 = oracle.discretize(D2, 0.0, 1.0)
+    it2, d2, c2, x2, _, _ = oracle.jacobi(A2, b2, x1, D2, 0.0, 1.0, 1e-3, 30000)
+    with pkg.Solver(128, 128) as s:
+        s.set_image(img00000)
+        s.assemble_2phase(1e-3, 100.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        r1 = s.solve(1e-3, 30000)
+        s.assemble_2phase(1e-3, 10000.0, 0.0, 1.0)
+        r2 = s.solve(1e-3, 30000)
+        assert (r1.iters, r1.deff_raw) == (it1, d1)
+        assert (r2.iters, r2.deff_raw, r2.conv) == (it2, d2, c2)
+        assert_field(s.get_field(), x2)
+
+
+# ------------------------------------------------ benchmark sizes (properties)
+
+@pytest.mark.parametrize("n", [128, 1024, 4096])
+def test_first_check_deff_at_benchmark_sizes(pkg, recorded, n):
+    """Device generator + assembly + one sweep + flux at BASELINE sizes against the
+    reference's recorded first-check Deff (bit-exact), for every kernel."""
+    want = recorded["synthetic_first_check_deff"][str(n)]
+    for kernel in KERNELS:
+        with pkg.Solver(n, n, kernel=kernel) as s:
+            s.synth_image(12345, 0)
+            s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            s.init_linear(0.0, 1.0)
+            r = s.solve(1e-6, 1)
+            assert r.iters == 1 and r.checks == 1
+            assert abs(r.deff_raw - want) / want <= DEFF_TOL
+            assert r.deff_raw == want, (kernel, n, repr(r.deff_raw))
+
+
+def test_kernels_agree_at_4096(pkg):
+    """Full benchmark size: the three kernels produce the same bits after 25 sweeps."""
+    fields = []
+    for kernel in KERNELS:
+        with pkg.Solver(4096, 4096, kernel=kernel) as s:
+            s.synth_image(12345, 0)
+            s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            s.init_linear(0.0, 1.0)
+            s.sweeps(25)
+            fields.append(s.get_field())
+    assert np.array_equal(fields[0], fields[1]) and np.array_equal(fields[0], fields[2])
+
+
+def test_parallel_stripes_analytic_at_2048(pkg):
+    """doc 5.3 eq. (7) at a large size: the linear guess is the exact solution of the
+    parallel-stripe problem, so Deff = eps*Df + (1-eps)*Ds after the minimum 10 001 sweeps."""
+    n, eps, Ds = 2048, 0.25, 1e-3
+    pix = np.full((n, n), 255, dtype=np.uint8)
+    pix[: int(eps * n), :] = 0
+    with pkg.Solver(n, n) as s:
+        s.set_image(pix)
+        s.assemble_2phase(Ds, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        r = s.solve(1e-6, 500000)
+        assert r.iters == 10001
+        exact = eps + (1 - eps) * Ds
+        assert abs(r.deff_raw - exact) / exact < 1e-11
+        assert abs(r.MFL.sum() - r.MFR.sum()) / abs(r.MFL.sum()) < 1e-11     # flux balance
+
+
+def test_mirror_symmetry_at_1024(pkg):
+    """Flipping the image top-bottom flips the field (N and S swap places in sigma,
+    so agreement is to rounding, not bitwise)."""
+    n = 1024
+    with pkg.Solver(n, n) as s:
+        s.synth_image(12345, 0)
+        pix = s.get_image()
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(200)
+        a = s.get_field()
+        s.set_image(np.ascontiguousarray(pix[::-1]))
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(200)
+        bflip = s.get_field()[::-1]
+    assert rel_l2(bflip, a) < 1e-13
+
+
+def test_errors_are_loud(pkg):
+    with pkg.Solver(16, 16) as s:
+        with pytest.raises(pkg.DeffError):
+            s.sweeps(1)                      # no field / system
+        s.init_linear(0.0, 1.0)
+        with pytest.raises(pkg.DeffError):
+            s.sweeps(1)                      # no system
+        with pytest.raises(pkg.DeffError):
+            s.set_image(np.zeros((8, 8), dtype=np.uint8))   # shape mismatch

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Kernel exploration on the GPU box: sweep rate per kernel / tuning / size.
+Writes one line per variant; interleaves variants over rounds (one process)."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import effectivediffusivityfvm_amd as pkg  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sizes", default="1024,4096")
+    ap.add_argument("--sweeps", type=int, default=200)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--variants", default="scalar,explicit,explicit:rows_explicit=8,explicit:rows_explicit=16,"
+                                          "explicit:rows_explicit=64,matfree,matfree:rows_matfree=8,"
+                                          "matfree:rows_matfree=16,matfree:rows_matfree=64")
+    args = ap.parse_args()
+    for n in [int(v) for v in args.sizes.split(",")]:
+        solvers = []
+        for var in args.variants.split(","):
+            parts = var.split(":")
+            s = pkg.Solver(n, n, kernel=parts[0])
+            for kv in parts[1:]:
+                k, v = kv.split("=")
+                s.set_tuning(k, int(v))
+            s.synth_image(12345, 0)
+            s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            s.init_linear(0.0, 1.0)
+            s.sweeps(10)
+            solvers.append((var, s, []))
+        for _ in range(args.rounds):
+            for var, s, times in solvers:
+                times.append(s.sweeps(args.sweeps) / args.sweeps)
+        for var, s, times in solvers:
+            best, med = min(times), sorted(times)[len(times) // 2]
+            rate = n * n / (med * 1e-3) / 1e6
+            print(f"n={n:6d} {var:40s} med {med*1e3:9.2f} us  min {best*1e3:9.2f} us  "
+                  f"{rate:10.0f} Mcells*iter/s  {rate*64/1e3:8.0f} GB/s@64B  frac {rate*64/8e6:.3f}", flush=True)
+            s.close()
+
+
+if __name__ == "__main__":
+    main()
