@@ -23,6 +23,7 @@
 #include "fvm_row.hpp"
 #include "kernels_setup.hpp"
 #include "kernels_sweep.hpp"
+#include "kernels_tb.hpp"
 
 using namespace deff;
 
@@ -78,6 +79,7 @@ struct deff_ctx {
     // matrix-free system
     uint8_t *code = nullptr;
     double *lut = nullptr;          // device copy of the tables
+    double *lut_tb = nullptr;       // device copy in the 16-class layout of kernels_tb.hpp
     std::vector<double> lut_a0;     // host: A0 plane per class/code (c0 = w/A0 on demand)
     std::vector<double> lut_host;   // host: full tables
     bool have_matfree = false;
@@ -101,7 +103,12 @@ struct deff_ctx {
     size_t scratch_bytes = 0;
 
     int kernel = DEFF_KERNEL_AUTO;
-    int rows_explicit = 0, rows_matfree = 0;     // 0 = default
+    int rows_explicit = 0, rows_matfree = 0;     // rows per register tile, 0 = default
+    int wg_matfree = 0;                          // persistent workgroups of the matrix-free kernel, 0 = default
+    int nt_explicit = 1;                         // non-temporal coefficient loads in the explicit kernels
+    int serpentine = 1;                          // alternate the tile walk direction from sweep to sweep
+    int tb_T = 0, tb_LY = 0, tb_wg = 0;          // temporal blocking: sweeps per pass, rows per chunk, workgroups
+    int64_t last_launches = 0;                   // sweep-kernel launches of the last deff_sweeps()/deff_solve()
 };
 
 static int use_device(const deff_ctx *c)
@@ -230,7 +237,7 @@ extern "C" int deff_destroy(deff_ctx *c)
     if (!c) return DEFF_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->pix, c->a0, c->c0, c->aW, c->aE, c->aS, c->aN, c->b, c->code, c->lut,
+    void *bufs[] = {c->pix, c->a0, c->c0, c->aW, c->aE, c->aS, c->aN, c->b, c->code, c->lut, c->lut_tb,
                     c->Dl, c->Dr, c->mf, c->x[0], c->x[1], c->scratch};
     for (void *p : bufs) if (p) (void)hipFree(p);
     if (c->mf_host) (void)hipHostFree(c->mf_host);
@@ -264,10 +271,11 @@ extern "C" int deff_set_kernel(deff_ctx *c, int kernel)
 static int resolve_kernel(const deff_ctx *c, int *k)
 {
     int want = c->kernel;
-    if (want == DEFF_KERNEL_MATFREE_TB) want = DEFF_KERNEL_MATFREE;   // TB lands in a later revision
-    if (want == DEFF_KERNEL_AUTO) want = c->have_matfree ? DEFF_KERNEL_MATFREE : DEFF_KERNEL_EXPLICIT;
-    if (want == DEFF_KERNEL_MATFREE) {
-        if (!c->have_matfree) return fail(DEFF_ESTATE, "matrix-free kernel needs deff_assemble_2phase()");
+    if (want == DEFF_KERNEL_AUTO) want = c->have_matfree ? DEFF_KERNEL_MATFREE_TB : DEFF_KERNEL_EXPLICIT;
+    if (want == DEFF_KERNEL_MATFREE || want == DEFF_KERNEL_MATFREE_TB) {
+        if (!c->have_matfree) return fail(DEFF_ESTATE, "matrix-free kernels need deff_assemble_2phase()");
+        // the temporally blocked kernel needs 16-B aligned strips (even nx) and a few rows to stream
+        if (want == DEFF_KERNEL_MATFREE_TB && ((c->nx & 1) || c->ny < 8)) want = DEFF_KERNEL_MATFREE;
     } else {
         if (!c->have_explicit && !c->have_matfree) return fail(DEFF_ESTATE, "no system assembled");
         if (want == DEFF_KERNEL_EXPLICIT && (c->nx & 1)) want = DEFF_KERNEL_SCALAR;   // 16-B rows need even nx
@@ -288,6 +296,12 @@ extern "C" int deff_set_tuning(deff_ctx *c, const char *key, int value)
     if (value < 0) return fail(DEFF_EINVAL, "tuning value must be >= 0");
     if (!strcmp(key, "rows_explicit")) c->rows_explicit = value;
     else if (!strcmp(key, "rows_matfree")) c->rows_matfree = value;
+    else if (!strcmp(key, "wg_matfree")) c->wg_matfree = (value + 7) / 8 * 8;
+    else if (!strcmp(key, "nt_explicit")) c->nt_explicit = value ? 1 : 0;
+    else if (!strcmp(key, "serpentine")) c->serpentine = value ? 1 : 0;
+    else if (!strcmp(key, "tb_T")) c->tb_T = value;
+    else if (!strcmp(key, "tb_LY")) c->tb_LY = value;
+    else if (!strcmp(key, "tb_wg")) c->tb_wg = (value + 7) / 8 * 8;
     else return fail(DEFF_EINVAL, "unknown tuning key '%s'", key);
     return DEFF_OK;
 }
@@ -374,7 +388,18 @@ static int upload_lut(deff_ctx *c, double omega)
     TRY(dev_alloc(&c->lut, (size_t)LUT_DOUBLES));
     HIP_TRY(hipMemcpyAsync(c->lut, c->lut_host.data(), sizeof(double) * LUT_DOUBLES, hipMemcpyHostToDevice,
                            c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));   // lut_host may be rewritten by the next call
+    // 16-class layout for the temporally blocked kernel: class 3 (outside the mesh) stays zero
+    std::vector<double> tb(TB_LUT_DOUBLES, 0.0);
+    for (int pl = 0; pl < LUT_PLANES; ++pl)
+        for (int y = 0; y < 3; ++y)
+            for (int xq = 0; xq < 3; ++xq)
+                for (int code = 0; code < LUT_CODES; ++code)
+                    tb[pl * TB_PLANE_STRIDE + (y * 4 + xq) * LUT_CODES + code] =
+                        c->lut_host[pl * LUT_PLANE_STRIDE + (y * 3 + xq) * LUT_CODES + code];
+    TRY(dev_alloc(&c->lut_tb, (size_t)TB_LUT_DOUBLES));
+    HIP_TRY(hipMemcpyAsync(c->lut_tb, tb.data(), sizeof(double) * TB_LUT_DOUBLES, hipMemcpyHostToDevice,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // host staging may be rewritten by the next call
     c->lut_omega = omega;
     return DEFF_OK;
 }
@@ -580,8 +605,45 @@ extern "C" int deff_synchronize(deff_ctx *c)
 struct SweepPlan {
     int kernel = 0;
     double omw = 0;
-    int rows = 0, gx = 0, gy = 0, blocks = 0;
+    int rows = 0, gx = 0, gy = 0, blocks = 0;       // single-sweep kernels
+    // temporally blocked kernel
+    int T = 0, LY = 0, ntx = 0, tgx = 0, tgy = 0, tblocks = 0;
+    bool guard = false;
+    // the reference's non-zero link test matters only when a phase cannot diffuse
+    static bool guard_probe(const deff_ctx *c)
+    {
+        return !(c->Ds > 0 && c->Df > 0 && std::isfinite(c->Ds) && std::isfinite(c->Df));
+    }
 };
+
+// Workgroups of the temporally blocked kernel that are resident at once on this device.
+template <int T, bool G>
+static int tb_occ(int *per_cu)
+{
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_sweep_matfree_tb<T, G>, 256, 0));
+    return DEFF_OK;
+}
+
+static int tb_resident_blocks(const deff_ctx *c, int T, bool guard, int *resident)
+{
+    int per_cu = 0, cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    switch (T) {
+    case 2: TRY(guard ? (tb_occ<2, true>(&per_cu)) : (tb_occ<2, false>(&per_cu))); break;
+    case 4: TRY(guard ? (tb_occ<4, true>(&per_cu)) : (tb_occ<4, false>(&per_cu))); break;
+    case 6: TRY(guard ? (tb_occ<6, true>(&per_cu)) : (tb_occ<6, false>(&per_cu))); break;
+    default: TRY(guard ? (tb_occ<8, true>(&per_cu)) : (tb_occ<8, false>(&per_cu))); break;
+    }
+    if (per_cu < 1) per_cu = 1;
+    *resident = per_cu * cus;
+    return DEFF_OK;
+}
+
+static int pick_R(int requested, int dflt)
+{
+    const int r = requested ? requested : dflt;
+    return r >= 8 ? 8 : r >= 4 ? 4 : r >= 2 ? 2 : 1;
+}
 
 static void tile_grid(const deff_ctx *c, int cols_per_block, int rows, SweepPlan *pl)
 {
@@ -592,25 +654,51 @@ static void tile_grid(const deff_ctx *c, int cols_per_block, int rows, SweepPlan
     pl->blocks = (int)(((total + 7u) / 8u) * 8u);      // see xcd_tile()
 }
 
-// Rows marched per workgroup: enough workgroups to fill 256 CUs several times
-// over, few enough that the halo rows (re-read by two workgroups) stay cheap.
-static int default_rows(const deff_ctx *c, int cols_per_block)
-{
-    const long gx = (c->nx + cols_per_block - 1) / cols_per_block;
-    int rows = 32;
-    while (rows > 4 && gx * ((c->ny + rows - 1) / rows) < 2048) rows >>= 1;
-    return rows;
-}
-
 static int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
 {
     if (!c->have_field) return fail(DEFF_ESTATE, "no field: call deff_init_linear() or deff_set_field()");
     TRY(resolve_kernel(c, &pl->kernel));
     pl->omw = 1.0 - omega;                              // cuh:89 evaluates (1.0 - w) in double
-    if (pl->kernel == DEFF_KERNEL_MATFREE) {
+    if (pl->kernel == DEFF_KERNEL_MATFREE || pl->kernel == DEFF_KERNEL_MATFREE_TB) {
         TRY(upload_lut(c, omega));
+        if (pl->kernel == DEFF_KERNEL_MATFREE_TB) {
+            int T = c->tb_T ? c->tb_T : 4;
+            T = T >= 8 ? 8 : T >= 6 ? 6 : T >= 4 ? 4 : 2;
+            pl->T = T;
+            pl->ntx = (c->nx + (TB_COLS - 2 * T) - 1) / (TB_COLS - 2 * T);
+            pl->tgx = (pl->ntx + 3) / 4;
+            // Rows per chunk.  Workgroups are persistent and tiles cost the same, so the
+            // pass takes rounds x (LY + 2T) row steps, where one round is as many block
+            // tiles as are resident at once.  Pick the (rounds, LY) pair minimising that.
+            int resident = c->tb_wg;
+            if (!resident) TRY(tb_resident_blocks(c, T, SweepPlan::guard_probe(c), &resident));
+            int LY = c->tb_LY;
+            if (!LY) {
+                long best_cost = -1;
+                for (int k = 1; k <= 8; ++k) {
+                    const int tgy_max = (int)(((long)k * resident) / pl->tgx);
+                    if (tgy_max < 1) continue;
+                    int ly = (c->ny + tgy_max - 1) / tgy_max;
+                    if (ly < 1) ly = 1;
+                    const long cost = (long)k * (ly + 2 * T);
+                    if (best_cost < 0 || cost < best_cost) { best_cost = cost; LY = ly; }
+                }
+                if (!LY) LY = c->ny;
+            }
+            if (LY > c->ny) LY = c->ny;
+            pl->LY = LY;
+            pl->tgy = (c->ny + LY - 1) / LY;
+            const unsigned total = (unsigned)pl->tgx * (unsigned)pl->tgy;
+            pl->tblocks = (int)(((total + 7u) / 8u) * 8u);
+            if (pl->tblocks > resident) pl->tblocks = resident >= 8 ? resident / 8 * 8 : 8;
+            // the reference's non-zero link test matters only when a phase cannot diffuse
+            pl->guard = SweepPlan::guard_probe(c);
+        }
         const int vec = (c->nx & 1) ? 1 : 2;
-        tile_grid(c, 256 * vec, c->rows_matfree ? c->rows_matfree : default_rows(c, 256 * vec), pl);
+        tile_grid(c, 256 * vec, pick_R(c->rows_matfree, c->n >= ((size_t)1 << 21) ? 8 : 2), pl);
+        // persistent grid: a few workgroups per CU walk the tiles (tables loaded once each)
+        const int cap = c->wg_matfree ? c->wg_matfree : 256 * 8;
+        if (pl->blocks > cap) pl->blocks = cap;
     } else {
         TRY(explicit_from_image(c));
         if (c->c0_omega != omega) {
@@ -620,7 +708,7 @@ static int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             c->c0_omega = omega;
         }
         if (pl->kernel == DEFF_KERNEL_EXPLICIT)
-            tile_grid(c, 512, c->rows_explicit ? c->rows_explicit : default_rows(c, 512), pl);
+            tile_grid(c, 512, pick_R(c->rows_explicit, 1), pl);
     }
     return DEFF_OK;
 }
@@ -631,25 +719,96 @@ static inline void enqueue_sweep(deff_ctx *c, const SweepPlan &pl)
     const double *xin = c->x[c->cur];
     double *xout = c->x[c->cur ^ 1];
     const CoefConst cf{c->c0, c->aW, c->aE, c->aS, c->aN, c->b};
+    const int flip = c->serpentine ? c->cur : 0;
     switch (pl.kernel) {
     case DEFF_KERNEL_SCALAR:
-        hipLaunchKernelGGL(k_sweep_scalar, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, cf,
-                           xin, xout, c->nx, c->n, pl.omw);
-        break;
-    case DEFF_KERNEL_EXPLICIT:
-        hipLaunchKernelGGL(k_sweep_explicit, dim3(pl.blocks), dim3(256), 0, c->stream, cf, xin, xout, c->nx,
-                           c->ny, pl.rows, pl.gx, pl.gy, pl.omw);
-        break;
-    default:
-        if (c->nx & 1)
-            hipLaunchKernelGGL(k_sweep_matfree<1>, dim3(pl.blocks), dim3(256), 0, c->stream, c->lut, c->code,
-                               xin, xout, c->nx, c->ny, pl.rows, pl.gx, pl.gy, pl.omw);
+        if (c->nt_explicit)
+            hipLaunchKernelGGL(k_sweep_scalar<true>, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
+                               cf, xin, xout, c->nx, c->n, pl.omw);
         else
-            hipLaunchKernelGGL(k_sweep_matfree<2>, dim3(pl.blocks), dim3(256), 0, c->stream, c->lut, c->code,
-                               xin, xout, c->nx, c->ny, pl.rows, pl.gx, pl.gy, pl.omw);
+            hipLaunchKernelGGL(k_sweep_scalar<false>, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
+                               cf, xin, xout, c->nx, c->n, pl.omw);
+        break;
+    case DEFF_KERNEL_EXPLICIT: {
+#define LAUNCH_EXPLICIT(R_)                                                                                  \
+    do {                                                                                                    \
+        if (c->nt_explicit)                                                                                 \
+            hipLaunchKernelGGL((k_sweep_explicit<R_, true>), dim3(pl.blocks), dim3(256), 0, c->stream, cf,  \
+                               xin, xout, c->nx, c->ny, pl.gx, pl.gy, flip, pl.omw);                        \
+        else                                                                                                \
+            hipLaunchKernelGGL((k_sweep_explicit<R_, false>), dim3(pl.blocks), dim3(256), 0, c->stream, cf, \
+                               xin, xout, c->nx, c->ny, pl.gx, pl.gy, flip, pl.omw);                        \
+    } while (0)
+        switch (pl.rows) {
+        case 1: LAUNCH_EXPLICIT(1); break;
+        case 2: LAUNCH_EXPLICIT(2); break;
+        case 4: LAUNCH_EXPLICIT(4); break;
+        default: LAUNCH_EXPLICIT(8); break;
+        }
+#undef LAUNCH_EXPLICIT
         break;
     }
+    default: {
+#define LAUNCH_MATFREE(V_, R_)                                                                               \
+    hipLaunchKernelGGL((k_sweep_matfree<V_, R_>), dim3(pl.blocks), dim3(256), 0, c->stream, c->lut, c->code, \
+                       xin, xout, c->nx, c->ny, pl.gx, pl.gy, flip, pl.omw)
+        if (c->nx & 1) {
+            switch (pl.rows) {
+            case 1: LAUNCH_MATFREE(1, 1); break;
+            case 2: LAUNCH_MATFREE(1, 2); break;
+            case 4: LAUNCH_MATFREE(1, 4); break;
+            default: LAUNCH_MATFREE(1, 8); break;
+            }
+        } else {
+            switch (pl.rows) {
+            case 1: LAUNCH_MATFREE(2, 1); break;
+            case 2: LAUNCH_MATFREE(2, 2); break;
+            case 4: LAUNCH_MATFREE(2, 4); break;
+            default: LAUNCH_MATFREE(2, 8); break;
+            }
+        }
+#undef LAUNCH_MATFREE
+        break;
+    }
+    }
     c->cur ^= 1;
+}
+
+// One temporally blocked pass: T sweeps, x[cur] -> x[cur^1].
+static inline void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl)
+{
+    const double *xin = c->x[c->cur];
+    double *xout = c->x[c->cur ^ 1];
+    const int flip = c->serpentine ? c->cur : 0;
+#define LAUNCH_TB(T_, G_)                                                                                      \
+    hipLaunchKernelGGL((k_sweep_matfree_tb<T_, G_>), dim3(pl.tblocks), dim3(256), 0, c->stream, c->lut_tb,     \
+                       c->code, xin, xout, c->nx, c->ny, pl.LY, pl.ntx, pl.tgx, pl.tgy, flip, pl.omw)
+    if (pl.guard) {
+        switch (pl.T) {
+        case 2: LAUNCH_TB(2, true); break;
+        case 4: LAUNCH_TB(4, true); break;
+        case 6: LAUNCH_TB(6, true); break;
+        default: LAUNCH_TB(8, true); break;
+        }
+    } else {
+        switch (pl.T) {
+        case 2: LAUNCH_TB(2, false); break;
+        case 4: LAUNCH_TB(4, false); break;
+        case 6: LAUNCH_TB(6, false); break;
+        default: LAUNCH_TB(8, false); break;
+        }
+    }
+#undef LAUNCH_TB
+    c->cur ^= 1;
+}
+
+// n sweeps: as many T-sweep passes as fit, the rest one at a time.
+static inline void enqueue_sweeps(deff_ctx *c, const SweepPlan &pl, int64_t n)
+{
+    if (pl.kernel == DEFF_KERNEL_MATFREE_TB) {
+        while (n >= pl.T) { enqueue_tb_pass(c, pl); n -= pl.T; ++c->last_launches; }
+    }
+    for (; n > 0; --n) { enqueue_sweep(c, pl); ++c->last_launches; }
 }
 
 extern "C" int deff_sweeps(deff_ctx *c, int64_t nsweeps, double omega, float *ms)
@@ -659,8 +818,9 @@ extern "C" int deff_sweeps(deff_ctx *c, int64_t nsweeps, double omega, float *ms
     TRY(use_device(c));
     SweepPlan pl;
     TRY(plan_sweeps(c, omega, &pl));
+    c->last_launches = 0;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    for (int64_t s = 0; s < nsweeps; ++s) enqueue_sweep(c, pl);
+    enqueue_sweeps(c, pl, nsweeps);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
@@ -713,13 +873,14 @@ extern "C" int deff_solve(deff_ctx *c, double omega, double tol, int64_t max_ite
     if (!c->have_walls) return fail(DEFF_ESTATE, "wall diffusivities unknown (needed for Deff)");
 
     int64_t iter = 0, checks = 0;
+    c->last_launches = 0;
     double deffNew = 1, deffOld = 5, change = 100.0, conv = 0;      // cuh:1171-1173
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     while (iter < max_iter && tol < fabs(change)) {                  // cuh:1232
         const int64_t next_check = ((iter + check_every - 1) / check_every) * check_every;
         const bool do_check = next_check < max_iter;
         const int64_t batch = do_check ? next_check - iter + 1 : max_iter - iter;
-        for (int64_t s = 0; s < batch; ++s) enqueue_sweep(c, pl);
+        enqueue_sweeps(c, pl, batch);
         HIP_TRY(hipGetLastError());
         iter += batch;
         if (do_check) {
@@ -739,5 +900,20 @@ extern "C" int deff_solve(deff_ctx *c, double omega, double tol, int64_t max_ite
     out->deff_raw = deffNew;                                         // cuh:1309: value at the last check
     out->conv = conv;
     out->loop_ms = ms;
+    return DEFF_OK;
+}
+
+extern "C" int deff_last_launches(const deff_ctx *c, int64_t *launches, int *sweeps_per_pass)
+{
+    if (!c || !launches) return fail(DEFF_EINVAL, "NULL argument");
+    *launches = c->last_launches;
+    if (sweeps_per_pass) {
+        int k = 0;
+        *sweeps_per_pass = 1;
+        if (resolve_kernel(c, &k) == DEFF_OK && k == DEFF_KERNEL_MATFREE_TB) {
+            int T = c->tb_T ? c->tb_T : 4;
+            *sweeps_per_pass = T >= 8 ? 8 : T >= 6 ? 6 : T >= 4 ? 4 : 2;
+        }
+    }
     return DEFF_OK;
 }

@@ -14,11 +14,11 @@
 //
 // Kernels:
 //   k_sweep_scalar    1 cell / thread, SoA coefficients, any nx
-//   k_sweep_explicit  2 cells / thread (16-B accesses), SoA coefficient
-//                     streams, each workgroup marches down `rows` rows keeping
-//                     the three x rows in registers: 64 B/cell/sweep of HBM
+//   k_sweep_explicit  2 x R cells / thread (16-B accesses), SoA coefficient
+//                     streams, all loads of a register tile issued up front:
+//                     64 B/cell/sweep of HBM
 //   k_sweep_matfree   coefficients looked up in an LDS table from a 1-byte
-//                     phase code: 17 B/cell/sweep of HBM
+//                     phase code, persistent workgroups: 17 B/cell/sweep of HBM
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -45,13 +45,19 @@ __device__ __forceinline__ double jacobi_cell(double c0, double aW, double aE, d
 // blocks id and id+8 share an L2.  Give every XCD a contiguous run of tiles in
 // column-major order (tiles above/below each other, which share halo rows of
 // x, then land in the same L2).  Placement only affects speed, never results.
-__device__ __forceinline__ bool xcd_tile(int gx, int gy, int &bx, int &by)
+//
+// flip = 1 walks every XCD's run backwards.  Alternating it from sweep to sweep
+// ("serpentine") makes a sweep start on the rows the previous sweep wrote last,
+// i.e. on the part of the field most likely still in L2 / Infinity Cache.
+__device__ __forceinline__ bool xcd_tile(int gx, int gy, int flip, int &bx, int &by)
 {
     const unsigned total = (unsigned)gx * (unsigned)gy;
     const unsigned per = (total + 7u) / 8u;
     const unsigned id = blockIdx.x;
-    const unsigned t = (id & 7u) * per + (id >> 3);
-    if ((id >> 3) >= per || t >= total) return false;
+    if ((id >> 3) >= per) return false;
+    const unsigned k = flip ? per - 1u - (id >> 3) : (id >> 3);
+    const unsigned t = (id & 7u) * per + k;
+    if (t >= total) return false;
     bx = (int)(t / (unsigned)gy);
     by = (int)(t % (unsigned)gy);
     return true;
@@ -59,6 +65,18 @@ __device__ __forceinline__ bool xcd_tile(int gx, int gy, int &bx, int &by)
 
 // ------------------------------------------------------------- scalar -----
 
+// NT = stream the coefficient planes with non-temporal loads: they are read
+// once per sweep and are 6x the size of x, so keeping them out of the caches
+// leaves L2 / Infinity Cache to the field, which is re-read by neighbours and by
+// the next sweep.
+template <bool NT>
+__device__ __forceinline__ double ldc(const double *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+template <bool NT>
 __global__ __launch_bounds__(256) void k_sweep_scalar(CoefConst c, const double *__restrict__ x,
                                                       double *__restrict__ xnew, int nx, size_t n,
                                                       double omw)
@@ -69,7 +87,8 @@ __global__ __launch_bounds__(256) void k_sweep_scalar(CoefConst c, const double 
     const double xe = (p + 1 < n) ? x[p + 1] : 0.0;
     const double xs = (p + nx < n) ? x[p + nx] : 0.0;
     const double xn = (p >= (size_t)nx) ? x[p - nx] : 0.0;
-    xnew[p] = jacobi_cell(c.c0[p], c.aW[p], c.aE[p], c.aS[p], c.aN[p], c.b[p], x[p], xw, xe, xs, xn, omw);
+    xnew[p] = jacobi_cell(ldc<NT>(c.c0 + p), ldc<NT>(c.aW + p), ldc<NT>(c.aE + p), ldc<NT>(c.aS + p),
+                          ldc<NT>(c.aN + p), ldc<NT>(c.b + p), x[p], xw, xe, xs, xn, omw);
 }
 
 // ----------------------------------------------------------- explicit -----
@@ -82,36 +101,62 @@ __device__ __forceinline__ void st2(double *p, double2 v)
 {
     *reinterpret_cast<double2 *>(p) = v;
 }
+template <bool NT>
+__device__ __forceinline__ double2 ldc2(const double *p)
+{
+    if constexpr (NT) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
+        return make_double2(v.x, v.y);
+    } else {
+        return ld2(p);
+    }
+}
 
-// Requires nx even (16-B aligned row starts).  Tile = 512 columns x `rows` rows.
+// Requires nx even (16-B aligned row starts).  Tile = 512 columns x R rows; every
+// thread owns a 2 x R register tile and issues all of its loads before the
+// first use, so (R+2) x-rows and 6R coefficient vectors are in flight per lane.
+// (A version that marched down many rows with a rolling 3-row window was
+// latency-bound: one dependent global round trip per row.)
+template <int R, bool NT>
 __global__ __launch_bounds__(256) void k_sweep_explicit(CoefConst c, const double *__restrict__ x,
                                                         double *__restrict__ xnew, int nx, int ny,
-                                                        int rows, int gx, int gy, double omw)
+                                                        int gx, int gy, int flip, double omw)
 {
     int bx, by;
-    if (!xcd_tile(gx, gy, bx, by)) return;
+    if (!xcd_tile(gx, gy, flip, bx, by)) return;
     const int col = (bx * 256 + (int)threadIdx.x) * 2;
     if (col >= nx) return;
-    const int r0 = by * rows;
-    const int r1 = min(r0 + rows, ny);
+    const int r0 = by * R;
     const size_t n = (size_t)nx * ny;
-    size_t p = (size_t)r0 * nx + col;
-
+    const size_t p0 = (size_t)r0 * nx + col;
     const double2 zero = make_double2(0.0, 0.0);
-    double2 xm = (p >= (size_t)nx) ? ld2(x + p - nx) : zero;
-    double2 xc = ld2(x + p);
-    for (int r = r0; r < r1; ++r, p += nx) {
-        const double2 xp = (p + nx < n) ? ld2(x + p + nx) : zero;
-        const double xw = (p >= 1) ? x[p - 1] : 0.0;
-        const double xe = (p + 2 < n) ? x[p + 2] : 0.0;
-        const double2 c0 = ld2(c.c0 + p), aW = ld2(c.aW + p), aE = ld2(c.aE + p);
-        const double2 aS = ld2(c.aS + p), aN = ld2(c.aN + p), b = ld2(c.b + p);
+
+    double2 xr[R + 2];
+    double xw[R], xe[R];
+    xr[0] = (p0 >= (size_t)nx) ? ld2(x + p0 - nx) : zero;
+#pragma unroll
+    for (int k = 0; k <= R; ++k) {
+        const size_t p = p0 + (size_t)k * nx;
+        xr[k + 1] = (p < n) ? ld2(x + p) : zero;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const size_t p = p0 + (size_t)k * nx;
+        xw[k] = (p >= 1 && p < n) ? x[p - 1] : 0.0;
+        xe[k] = (p + 2 < n) ? x[p + 2] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        if (r0 + k >= ny) break;
+        const size_t p = p0 + (size_t)k * nx;
+        const double2 c0 = ldc2<NT>(c.c0 + p), aW = ldc2<NT>(c.aW + p), aE = ldc2<NT>(c.aE + p);
+        const double2 aS = ldc2<NT>(c.aS + p), aN = ldc2<NT>(c.aN + p), b = ldc2<NT>(c.b + p);
+        const double2 xm = xr[k], xc = xr[k + 1], xp = xr[k + 2];
         double2 o;
-        o.x = jacobi_cell(c0.x, aW.x, aE.x, aS.x, aN.x, b.x, xc.x, xw, xc.y, xp.x, xm.x, omw);
-        o.y = jacobi_cell(c0.y, aW.y, aE.y, aS.y, aN.y, b.y, xc.y, xc.x, xe, xp.y, xm.y, omw);
+        o.x = jacobi_cell(c0.x, aW.x, aE.x, aS.x, aN.x, b.x, xc.x, xw[k], xc.y, xp.x, xm.x, omw);
+        o.y = jacobi_cell(c0.y, aW.y, aE.y, aS.y, aN.y, b.y, xc.y, xc.x, xe[k], xp.y, xm.y, omw);
         st2(xnew + p, o);
-        xm = xc;
-        xc = xp;
     }
 }
 
@@ -135,61 +180,104 @@ __device__ __forceinline__ double jacobi_cell_lut(const double *lut, int idx, do
                        lut[idx + 5 * LUT_PLANE_STRIDE], xc, xw, xe, xs, xn, omw);
 }
 
-// VEC = 2 needs nx even; VEC = 1 handles any nx.  Tile = 256*VEC columns x rows.
-template <int VEC>
+// Tile -> XCD map for persistent grids: workgroup `wg` of `nwg` walks tiles
+// t = wg, wg + nwg, ...; tiles are numbered so that the tiles of one XCD (wg & 7)
+// form a contiguous column-major run (same idea as xcd_tile()).
+__device__ __forceinline__ void tile_coords(unsigned t, int gy, int &bx, int &by)
+{
+    bx = (int)(t / (unsigned)gy);
+    by = (int)(t % (unsigned)gy);
+}
+
+// VEC = 2 needs nx even; VEC = 1 handles any nx.  Tile = 256*VEC columns x R
+// rows.  Persistent: the grid is a few workgroups per CU, each loads the tables
+// into LDS once and then walks its share of the tiles.
+template <int VEC, int R>
 __global__ __launch_bounds__(256) void k_sweep_matfree(const double *__restrict__ lut_g,
                                                        const uint8_t *__restrict__ code,
                                                        const double *__restrict__ x,
                                                        double *__restrict__ xnew, int nx, int ny,
-                                                       int rows, int gx, int gy, double omw)
+                                                       int gx, int gy, int flip, double omw)
 {
     __shared__ double lut[LUT_DOUBLES];
     for (int k = threadIdx.x; k < LUT_DOUBLES; k += 256) lut[k] = lut_g[k];
     __syncthreads();
 
-    int bx, by;
-    if (!xcd_tile(gx, gy, bx, by)) return;
-    const int col = (bx * 256 + (int)threadIdx.x) * VEC;
-    if (col >= nx) return;
-    const int r0 = by * rows;
-    const int r1 = min(r0 + rows, ny);
     const size_t n = (size_t)nx * ny;
-    size_t p = (size_t)r0 * nx + col;
+    const unsigned total = (unsigned)gx * (unsigned)gy;
+    const unsigned per = (total + 7u) / 8u;              // tiles per XCD
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned nper = gridDim.x >> 3;                // workgroups per XCD (grid is a multiple of 8)
+    for (unsigned k = blockIdx.x >> 3; k < per; k += nper) {
+        const unsigned t = xcd * per + (flip ? per - 1u - k : k);
+        if (t >= total) continue;
+        int bx, by;
+        tile_coords(t, gy, bx, by);
+        const int col = (bx * 256 + (int)threadIdx.x) * VEC;
+        if (col >= nx) continue;
+        const int r0 = by * R;
+        const size_t p0 = (size_t)r0 * nx + col;
 
-    if constexpr (VEC == 2) {
-        const int xcls0 = (col == 0) ? 1 : 0;                 // cell 0 can only be the first column
-        const int xcls1 = (col + 1 == nx - 1) ? 2 : 0;        // cell 1 can only be the last column
-        const double2 zero = make_double2(0.0, 0.0);
-        double2 xm = (p >= (size_t)nx) ? ld2(x + p - nx) : zero;
-        double2 xc = ld2(x + p);
-        for (int r = r0; r < r1; ++r, p += nx) {
-            const double2 xp = (p + nx < n) ? ld2(x + p + nx) : zero;
-            const double xw = (p >= 1) ? x[p - 1] : 0.0;
-            const double xe = (p + 2 < n) ? x[p + 2] : 0.0;
-            const unsigned cc = *reinterpret_cast<const uint16_t *>(code + p);
-            const int ycls = (r == 0) ? 1 : (r == ny - 1 ? 2 : 0);
-            const int i0 = (ycls * 3 + xcls0) * LUT_CODES + (int)(cc & 31u);
-            const int i1 = (ycls * 3 + xcls1) * LUT_CODES + (int)((cc >> 8) & 31u);
-            double2 o;
-            o.x = jacobi_cell_lut(lut, i0, xc.x, xw, xc.y, xp.x, xm.x, omw);
-            o.y = jacobi_cell_lut(lut, i1, xc.y, xc.x, xe, xp.y, xm.y, omw);
-            st2(xnew + p, o);
-            xm = xc;
-            xc = xp;
-        }
-    } else {
-        const int xcls = (col == 0) ? 1 : (col == nx - 1 ? 2 : 0);
-        double xm = (p >= (size_t)nx) ? x[p - nx] : 0.0;
-        double xc = x[p];
-        for (int r = r0; r < r1; ++r, p += nx) {
-            const double xp = (p + nx < n) ? x[p + nx] : 0.0;
-            const double xw = (p >= 1) ? x[p - 1] : 0.0;
-            const double xe = (p + 1 < n) ? x[p + 1] : 0.0;
-            const int ycls = (r == 0) ? 1 : (r == ny - 1 ? 2 : 0);
-            const int i0 = (ycls * 3 + xcls) * LUT_CODES + (int)(code[p] & 31u);
-            xnew[p] = jacobi_cell_lut(lut, i0, xc, xw, xe, xp, xm, omw);
-            xm = xc;
-            xc = xp;
+        if constexpr (VEC == 2) {
+            const int xcls0 = (col == 0) ? 1 : 0;              // cell 0 can only be the first column
+            const int xcls1 = (col + 1 == nx - 1) ? 2 : 0;     // cell 1 can only be the last column
+            const double2 zero = make_double2(0.0, 0.0);
+            double2 xr[R + 2];
+            double xw[R], xe[R];
+            unsigned cc[R];
+            xr[0] = (p0 >= (size_t)nx) ? ld2(x + p0 - nx) : zero;
+#pragma unroll
+            for (int q = 0; q <= R; ++q) {
+                const size_t p = p0 + (size_t)q * nx;
+                xr[q + 1] = (p < n) ? ld2(x + p) : zero;
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const size_t p = p0 + (size_t)q * nx;
+                xw[q] = (p >= 1 && p < n) ? x[p - 1] : 0.0;
+                xe[q] = (p + 2 < n) ? x[p + 2] : 0.0;
+                cc[q] = (p < n) ? *reinterpret_cast<const uint16_t *>(code + p) : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int r = r0 + q;
+                if (r >= ny) break;
+                const size_t p = p0 + (size_t)q * nx;
+                const int ycls = (r == 0) ? 1 : (r == ny - 1 ? 2 : 0);
+                const int i0 = (ycls * 3 + xcls0) * LUT_CODES + (int)(cc[q] & 31u);
+                const int i1 = (ycls * 3 + xcls1) * LUT_CODES + (int)((cc[q] >> 8) & 31u);
+                const double2 xm = xr[q], xc = xr[q + 1], xp = xr[q + 2];
+                double2 o;
+                o.x = jacobi_cell_lut(lut, i0, xc.x, xw[q], xc.y, xp.x, xm.x, omw);
+                o.y = jacobi_cell_lut(lut, i1, xc.y, xc.x, xe[q], xp.y, xm.y, omw);
+                st2(xnew + p, o);
+            }
+        } else {
+            const int xcls = (col == 0) ? 1 : (col == nx - 1 ? 2 : 0);
+            double xr[R + 2], xw[R], xe[R];
+            unsigned cc[R];
+            xr[0] = (p0 >= (size_t)nx) ? x[p0 - nx] : 0.0;
+#pragma unroll
+            for (int q = 0; q <= R; ++q) {
+                const size_t p = p0 + (size_t)q * nx;
+                xr[q + 1] = (p < n) ? x[p] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const size_t p = p0 + (size_t)q * nx;
+                xw[q] = (p >= 1 && p < n) ? x[p - 1] : 0.0;
+                xe[q] = (p + 1 < n) ? x[p + 1] : 0.0;
+                cc[q] = (p < n) ? code[p] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int r = r0 + q;
+                if (r >= ny) break;
+                const size_t p = p0 + (size_t)q * nx;
+                const int ycls = (r == 0) ? 1 : (r == ny - 1 ? 2 : 0);
+                const int i0 = (ycls * 3 + xcls) * LUT_CODES + (int)(cc[q] & 31u);
+                xnew[p] = jacobi_cell_lut(lut, i0, xr[q + 1], xw[q], xe[q], xr[q + 2], xr[q], omw);
+            }
         }
     }
 }

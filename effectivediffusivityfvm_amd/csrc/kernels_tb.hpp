@@ -1,0 +1,199 @@
+// kernels_tb.hpp -- matrix-free sweeps with temporal blocking: T weighted-Jacobi
+// sweeps per pass over HBM (gfx950, wave64, FP64).
+//
+// Legal because the reference only inspects the field every 10 000 sweeps
+// (Deff2DGPU/Deff2D.cuh:1243); each of the T sweeps is the same updateX_SOR
+// arithmetic (cuh:69-92) as the single-sweep kernels, so results stay
+// bit-identical -- a cell's value after sweep k does not depend on which kernel
+// produced it.
+//
+// Structure: every WAVE is independent.  A wave owns a strip of 128 columns
+// (2 per lane) and streams down the rows of its chunk.  Per input row it
+//   level 0   loads the row of x (16 B per lane, coalesced) and its phase codes,
+//   level t   (t = 1..T) computes row r-t of sweep t from the three newest rows
+//             of sweep t-1, all held in registers (a 3-row window per level);
+//             W/E neighbours come from the adjacent lanes by DPP wave shifts,
+//             N/S from the window; coefficients from the LDS lookup tables,
+//   level T   is stored (16 B per lane).
+// After t sweeps the outermost t columns/rows of a strip are stale, so a strip
+// produces 128 - 2T valid columns and needs T extra rows above and below its
+// chunk: neighbouring strips overlap by 2T and recompute the overlap instead of
+// synchronising.  No barrier, no inter-wave traffic inside the row loop.
+//
+// HBM traffic per cell per sweep: (8 + 1) / T / efficiency read + 8 / T
+// written -- ~5 B at T = 4 against 17 B for the single-sweep matrix-free
+// kernel and 64 B for explicit coefficients; the kernel is VALU/LDS-bound.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels_sweep.hpp"
+
+namespace deff {
+
+// Tables for this kernel: 6 planes x 16 position classes (ycls*4 + xcls, class 3
+// = outside the mesh: all zeros, so such cells stay exactly 0) x 32 codes.
+// The plane stride is padded to 520 doubles on purpose: with a stride that is a
+// multiple of 512 B hipcc fuses the six per-cell lookups into ds_read2st64_b64,
+// which banks on 32 banks (2-way conflicts on a 32-entry x 8-B group, 16 LDS
+// cycles per instruction, measured as THE bottleneck of this kernel); with 4160 B
+// neither ds_read2 form can encode the offset, the lookups stay plain
+// ds_read_b64 (64 banks: a 256-B group is conflict-free, 2 cycles each).
+constexpr int TB_CLASSES = 16;
+constexpr int TB_PLANE_STRIDE = TB_CLASSES * LUT_CODES + 8;    // 520 doubles
+constexpr int TB_LUT_DOUBLES = LUT_PLANES * TB_PLANE_STRIDE;   // 3120 doubles = 24.4 KiB
+constexpr int TB_COLS = 128;                                // columns per wave strip
+
+// lane i <- lane i-1 (lane 0 <- 0.0)
+__device__ __forceinline__ double from_lane_below(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// lane i <- lane i+1 (lane 63 <- 0.0)
+__device__ __forceinline__ double from_lane_above(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// One cell.  GUARD = reference's non-zero test on every link (needed when a
+// phase has zero diffusivity: links are -0.0 and neighbours may hold NaN/Inf,
+// cuh:77).  Without it a zero link multiplies a finite value and adds +-0,
+// which leaves sigma unchanged, so both forms give the same bits.
+template <bool GUARD>
+__device__ __forceinline__ double tb_cell(const double *lut, int idx, double xc, double xw, double xe,
+                                          double xs, double xn, double omw)
+{
+    const double c0 = lut[idx];
+    const double aW = lut[idx + TB_PLANE_STRIDE], aE = lut[idx + 2 * TB_PLANE_STRIDE];
+    const double aS = lut[idx + 3 * TB_PLANE_STRIDE], aN = lut[idx + 4 * TB_PLANE_STRIDE];
+    const double b = lut[idx + 5 * TB_PLANE_STRIDE];
+    if constexpr (GUARD) {
+        return jacobi_cell(c0, aW, aE, aS, aN, b, xc, xw, xe, xs, xn, omw);
+    } else {
+        double sigma = 0;
+        sigma += aW * xw;
+        sigma += aE * xe;
+        sigma += aS * xs;
+        sigma += aN * xn;
+        return omw * xc + c0 * (b - sigma);
+    }
+}
+
+__device__ __forceinline__ int tb_ycls(int r, int ny)
+{
+    return (r < 0 || r >= ny) ? 3 : (r == 0 ? 1 : (r == ny - 1 ? 2 : 0));
+}
+
+// grid: persistent workgroups of 4 waves; wave w of block-tile (btx, bty) owns
+// strip tx = btx*4 + w and rows [bty*LY, bty*LY + LY).  nx must be even, T even.
+template <int T, bool GUARD>
+__global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restrict__ lut_g,
+                                                          const uint8_t *__restrict__ code,
+                                                          const double *__restrict__ x,
+                                                          double *__restrict__ xnew, int nx, int ny,
+                                                          int LY, int ntx, int gx, int gy, int flip,
+                                                          double omw)
+{
+    static_assert(T >= 1 && T <= 8, "T out of range");
+    __shared__ double lut[TB_LUT_DOUBLES];
+    for (int k = threadIdx.x; k < TB_LUT_DOUBLES; k += 256) lut[k] = lut_g[k];
+    __syncthreads();
+
+    constexpr int WOUT = TB_COLS - 2 * T;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const unsigned total = (unsigned)gx * (unsigned)gy;
+    const unsigned per = (total + 7u) / 8u;
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned nper = gridDim.x >> 3;
+
+    for (unsigned kk = blockIdx.x >> 3; kk < per; kk += nper) {
+        const unsigned bt = xcd * per + (flip ? per - 1u - kk : kk);
+        if (bt >= total) continue;
+        const int btx = (int)(bt / (unsigned)gy), bty = (int)(bt % (unsigned)gy);
+        const int tx = btx * 4 + wave;
+        if (tx >= ntx) continue;                       // wave-uniform
+
+        const int cx0 = tx * WOUT;                     // first output column of the strip
+        const int col = cx0 - T + 2 * lane;            // this lane's first column (even)
+        const bool in_x = (col >= 0) && (col < nx);    // nx even => col+1 < nx too
+        const int ry0 = bty * LY;
+        const int ry1 = min(ry0 + LY, ny);
+        const int r_begin = ry0 - T, r_end = ry1 + T;  // input rows [r_begin, r_end)
+        const bool st_x = in_x && (col >= cx0) && (col < cx0 + WOUT);
+        // x position classes of the two cells (3 = outside the mesh)
+        const int xoff0 = (!in_x ? 3 : (col == 0 ? 1 : 0)) * LUT_CODES;
+        const int xoff1 = (!in_x ? 3 : (col + 1 == nx - 1 ? 2 : 0)) * LUT_CODES;
+        const double2 zero = make_double2(0.0, 0.0);
+
+        double2 w[T][3];                               // w[t]: 3 newest rows of sweep t
+        unsigned cw[T + 1];                            // cw[t]: codes of row r-t
+#pragma unroll
+        for (int t = 0; t < T; ++t) { w[t][0] = zero; w[t][1] = zero; w[t][2] = zero; }
+#pragma unroll
+        for (int t = 0; t <= T; ++t) cw[t] = 0u;
+
+        // prefetch the first group of three rows
+        double2 nx_x[3];
+        unsigned nx_c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int rr = r_begin + k;
+            const bool ok = in_x && rr >= 0 && rr < ny && rr < r_end;
+            const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col : 0);
+            nx_x[k] = ok ? ld2(x + p) : zero;
+            nx_c[k] = ok ? (unsigned)*reinterpret_cast<const uint16_t *>(code + p) : 0u;
+        }
+
+        for (int r = r_begin; r < r_end; r += 3) {
+            double2 cur_x[3];
+            unsigned cur_c[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { cur_x[k] = nx_x[k]; cur_c[k] = nx_c[k]; }
+            // issue the next group's loads before working on this one
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int rr = r + 3 + k;
+                const bool ok = in_x && rr >= 0 && rr < ny && rr < r_end;
+                const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col : 0);
+                nx_x[k] = ok ? ld2(x + p) : zero;
+                nx_c[k] = ok ? (unsigned)*reinterpret_cast<const uint16_t *>(code + p) : 0u;
+            }
+#pragma unroll
+            for (int ph = 0; ph < 3; ++ph) {
+                const int rr = r + ph;                 // input row of this step
+                // slots: newest = ph, previous = (ph+2)%3, oldest = (ph+1)%3
+                const int sN = (ph + 1) % 3, sC = (ph + 2) % 3, sS = ph;
+#pragma unroll
+                for (int t = T; t >= 1; --t) cw[t] = cw[t - 1];
+                cw[0] = cur_c[ph];
+                w[0][sS] = cur_x[ph];
+#pragma unroll
+                for (int t = 1; t <= T; ++t) {
+                    const int rt = rr - t;             // row produced by sweep t in this step
+                    const double2 vN = w[t - 1][sN], vC = w[t - 1][sC], vS = w[t - 1][sS];
+                    const double xw0 = from_lane_below(vC.y);
+                    const double xe1 = from_lane_above(vC.x);
+                    const int ybase = tb_ycls(rt, ny) * 4 * LUT_CODES;
+                    const int i0 = ybase + xoff0 + (int)(cw[t] & 31u);
+                    const int i1 = ybase + xoff1 + (int)((cw[t] >> 8) & 31u);
+                    double2 o;
+                    o.x = tb_cell<GUARD>(lut, i0, vC.x, xw0, vC.y, vS.x, vN.x, omw);
+                    o.y = tb_cell<GUARD>(lut, i1, vC.y, vC.x, xe1, vS.y, vN.y, omw);
+                    if (t < T) {
+                        w[t][sS] = o;
+                    } else if (st_x && rt >= ry0 && rt < ry1) {
+                        st2(xnew + (size_t)rt * nx + col, o);
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace deff

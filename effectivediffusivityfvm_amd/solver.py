@@ -142,6 +142,13 @@ class Solver:
                                 MFR.ctypes.data_as(C.c_void_p)))
         return d.value, MFL, MFR
 
+    def last_launches(self):
+        """(kernel launches of the last sweeps()/solve(), sweeps per temporally blocked launch)."""
+        n = C.c_int64()
+        t = C.c_int()
+        check(self._L.deff_last_launches(self._ctx, C.byref(n), C.byref(t)))
+        return n.value, t.value
+
     def device_field_ptr(self):
         p = C.c_void_p()
         pitch = C.c_size_t()

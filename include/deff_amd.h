@@ -108,6 +108,9 @@ int deff_solve(deff_ctx *ctx, double omega, double tol, int64_t max_iter, int64_
  * time on the context's stream), and one flux / Deff evaluation (cuh:1252-1263) */
 int deff_sweeps(deff_ctx *ctx, int64_t n, double omega, float *ms);
 int deff_flux(deff_ctx *ctx, double *deff_raw, double *MFL, double *MFR);
+/* sweep-kernel launches issued by the last deff_sweeps()/deff_solve() and the sweeps one
+ * temporally blocked launch performs (1 for the single-sweep kernels) */
+int deff_last_launches(const deff_ctx *ctx, int64_t *launches, int *sweeps_per_pass);
 
 /* raw device pointers for zero-copy interop (torch tensors, RCCL): current field,
  * and the byte pitch between rows (nx*8: rows are dense) */

@@ -15,9 +15,10 @@ def main():
     ap.add_argument("--sizes", default="1024,4096")
     ap.add_argument("--sweeps", type=int, default=200)
     ap.add_argument("--rounds", type=int, default=3)
-    ap.add_argument("--variants", default="scalar,explicit,explicit:rows_explicit=8,explicit:rows_explicit=16,"
-                                          "explicit:rows_explicit=64,matfree,matfree:rows_matfree=8,"
-                                          "matfree:rows_matfree=16,matfree:rows_matfree=64")
+    ap.add_argument("--variants", default="explicit,matfree,"
+                                          "matfree_tb:tb_T=2,matfree_tb:tb_T=4,matfree_tb:tb_T=6,matfree_tb:tb_T=8,"
+                                          "matfree_tb:tb_T=4:tb_LY=32,matfree_tb:tb_T=4:tb_LY=64,"
+                                          "matfree_tb:tb_T=8:tb_LY=64,matfree_tb:tb_T=8:tb_LY=128")
     args = ap.parse_args()
     for n in [int(v) for v in args.sizes.split(",")]:
         solvers = []
@@ -34,7 +35,7 @@ def main():
             solvers.append((var, s, []))
         for _ in range(args.rounds):
             for var, s, times in solvers:
-                times.append(s.sweeps(args.sweeps) / args.sweeps)
+                times.append(s.sweeps(args.sweeps) / args.sweeps)   # ms per sweep
         for var, s, times in solvers:
             best, med = min(times), sorted(times)[len(times) // 2]
             rate = n * n / (med * 1e-3) / 1e6
