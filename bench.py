@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "explicit", "scalar", "matfree", "matfree_tb"])
     ap.add_argument("--omega", type=float, default=2.0 / 3.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--explicit-sweeps", type=int, default=300,
+                    help="sweeps of the secondary explicit-coefficient measurement (0 = skip)")
     ap.add_argument("--tune", action="append", default=[], help="key=value tuning knob (repeatable)")
     args = ap.parse_args()
 
@@ -118,11 +120,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    launches, sweeps_per_launch = s.last_launches()     # of the last step
+    kernel_used = s.kernel_in_use()
+
+    # Secondary, untimed-by-the-driver leg: the explicit-coefficient kernel, i.e. the
+    # operator exactly as it sits behind the reference's seam (A, b streamed: 64 B/cell/sweep).
+    explicit = None
+    if args.explicit_sweeps > 0 and kernel_used != "explicit":
+        s.set_kernel("explicit")
+        s.sweeps(20, args.omega)
+        ems = s.sweeps(args.explicit_sweeps, args.omega)
+        explicit = (ems * 1e-3 / args.explicit_sweeps, s.kernel_in_use())
+        s.set_kernel(args.kernel)
+
     if rank == 0:
         cells = float(n) * n
-        launches = args.steps * S
-        launch_s = kernel_ms * 1e-3 / launches            # avg duration of one sweep launch (HIP events)
-        achieved = BYTES_PER_CELL_SWEEP * cells / launch_s / 1e9
+        total_launches = args.steps * launches
+        launch_s = kernel_ms * 1e-3 / total_launches      # avg duration of one sweep-kernel launch (HIP events)
+        alg_bytes = BYTES_PER_CELL_SWEEP * cells * sweeps_per_launch
+        achieved = alg_bytes / launch_s / 1e9
+
+        def traffic_of(kname):
+            tfile = os.path.join(ROOT, "profiles", "traffic.json")
+            try:
+                return json.load(open(tfile)).get(f"{kname}_{n}")
+            except Exception:
+                return None
+
         out = {
             "metric": "Mcells*iter/s (Jacobi sweep) at 4096^2" if n == 4096 else f"Mcells*iter/s (Jacobi sweep) at {n}^2",
             "value": world * cells * S * args.steps / elapsed / 1e6,
@@ -140,8 +164,9 @@ def main():
                 "workload": f"{n}x{n} synthetic two-phase image (splitmix64 seed 12345, porosity 0.5), Ds=1e-3 Df=1 "
                             f"CL=0 CR=1, omega={args.omega:.6g}; step = {S} sweeps + 1 Deff evaluation; "
                             f"one image per GPU (image index = rank)",
-                "kernel": s.kernel_in_use(),
+                "kernel": kernel_used,
                 "sweeps_per_step": S,
+                "sweeps_per_launch": sweeps_per_launch,
                 "deff_raw_after_run": deff,
             },
             "roofline": {
@@ -151,20 +176,44 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "kernel": s.kernel_in_use(),
+                "kernel": kernel_used,
                 "launch_us": launch_s * 1e6,
-                "algorithmic_bytes_per_launch": BYTES_PER_CELL_SWEEP * cells,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "model": "64 B per cell per sweep (A 40 + b 8 + x 8 read, xNew 8 written: the explicit operator "
+                         "behind the reference seam, SURVEY.md 8d) x cells x sweeps per launch",
             },
         }
-        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic_file):
-            try:
-                tr = json.load(open(traffic_file)).get(f"{s.kernel_in_use()}_{n}")
-                if tr:
-                    out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = tr.get("source")
-            except Exception:
-                pass
+        if kernel_used in ("matfree", "matfree_tb"):
+            # this kernel never materialises A: its own compulsory traffic is x 8 + code 1 read, xNew 8
+            # written per cell per LAUNCH (a temporally blocked launch does sweeps_per_launch sweeps on it)
+            own = 17.0 * cells
+            out["roofline"]["own_model"] = {
+                "bytes_per_launch": own,
+                "achieved": own / launch_s / 1e9,
+                "frac": own / launch_s / 1e9 / HBM_PEAK_GBS,
+                "note": "matrix-free: coefficients come from a 1-byte phase code through LDS tables; frac of the "
+                        "64-B model above can exceed 1 because those bytes are never moved",
+            }
+        tr = traffic_of(kernel_used)
+        if tr:
+            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = tr.get("source")
+        if explicit:
+            el, ek = explicit
+            ea = BYTES_PER_CELL_SWEEP * cells / el / 1e9
+            out["explicit_operator"] = {
+                "kernel": ek,
+                "value": cells / el / 1e6,
+                "unit": "Mcells*iter/s",
+                "sample": f"{args.explicit_sweeps} sweeps, same image, same run",
+                "roofline": {"bound": "hbm", "achieved": ea, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": ea / HBM_PEAK_GBS, "launch_us": el * 1e6,
+                             "algorithmic_bytes_per_launch": BYTES_PER_CELL_SWEEP * cells, "traffic": None},
+            }
+            tr = traffic_of(ek)
+            if tr:
+                out["explicit_operator"]["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                out["explicit_operator"]["roofline"]["traffic_source"] = tr.get("source")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n)
         print(json.dumps(out), flush=True)

@@ -21,7 +21,7 @@ SYMBOLS = [
     "deff_set_tuning", "deff_set_image", "deff_synth_image", "deff_get_image",
     "deff_assemble_2phase", "deff_assemble_from_D", "deff_set_system", "deff_get_system",
     "deff_init_linear", "deff_set_field", "deff_get_field", "deff_solve", "deff_sweeps",
-    "deff_flux", "deff_last_launches", "deff_device_field", "deff_synchronize",
+    "deff_flux", "deff_set_progress", "deff_last_launches", "deff_device_field", "deff_synchronize",
 ]
 
 
@@ -36,6 +36,7 @@ class Result(C.Structure):
                 ("conv", C.c_double), ("loop_ms", C.c_double)]
 
 
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_int64, C.c_double, C.c_double, C.c_void_p)
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 _lib = None
@@ -78,6 +79,7 @@ def load():
                              C.c_void_p, C.c_void_p]
     L.deff_sweeps.argtypes = [ctx, C.c_int64, C.c_double, C.POINTER(C.c_float)]
     L.deff_flux.argtypes = [ctx, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
+    L.deff_set_progress.argtypes = [ctx, PROGRESS_FN, C.c_void_p]
     L.deff_last_launches.argtypes = [ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int)]
     L.deff_device_field.argtypes = [ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.deff_synchronize.argtypes = [ctx]

@@ -1,0 +1,64 @@
+"""Dataset-generation (batch) mode across GPUs: whole images per rank, no data-path
+collective (reference BatchSim, Deff2D.cuh:1843-2054).
+
+Image k goes to rank k mod world; every rank reuses ONE solver context for all of
+its images (the reference re-allocates and resets the device per image,
+cuh:1975/cuh:2038); results land in the reference's NumImg x 9 table by image index,
+so the output order does not depend on the number of ranks.  The only
+communication is the final gather of that small table (torch.distributed: RCCL on
+GPUs, gloo in the CPU tests).
+"""
+import numpy as np
+
+# BatchSim's output row, cuh:2026-2034
+COLUMNS = ("imgNum", "porosity", "PathFlag", "Deff", "Time", "nElements", "converge", "ds", "df")
+
+
+def shard(num_images, rank, world):
+    """Image indices owned by `rank` (round-robin, deterministic)."""
+    return list(range(rank, num_images, world))
+
+
+def solve_image(solver, pix, Ds, Df, CL, CR, tol, max_iter, omega=2.0 / 3.0):
+    """One BatchSim iteration on an already-created context: image -> assembly ->
+    linear guess -> solve.  Returns (deff normalised by Df (cuh:2017), conv, iters, loop_ms)."""
+    solver.set_image(pix)
+    solver.assemble_2phase(Ds, Df, CL, CR)
+    solver.init_linear(CL, CR)                       # cuh:1955-1959
+    r = solver.solve(tol, max_iter, omega=omega)
+    return r.deff_raw / Df, r.conv, r.iters, r.loop_ms
+
+
+def run_batch(solver, load_image, num_images, Ds, Df, CL, CR, tol, max_iter, rank=0, world=1, dist=None,
+              device=None):
+    """Solve images rank, rank+world, ... and gather the table on rank 0.
+
+    load_image(k) -> uint8 (H, W) pixels of image k (stb-decoded JPEG or synthetic).
+    Returns the (num_images, 9) table on rank 0, None elsewhere.
+    """
+    mine = shard(num_images, rank, world)
+    rows = np.zeros((len(mine), len(COLUMNS)))
+    for slot, k in enumerate(mine):
+        pix = load_image(k)
+        porosity = float(np.count_nonzero(pix < 150)) / pix.size            # calcPorosity cuh:383-408
+        deff, conv, iters, ms = solve_image(solver, pix, Ds, Df, CL, CR, tol, max_iter)
+        rows[slot] = (k, porosity, -1.0,          # PathFlag needs FloodFill (cuh:557-713): not computed here
+                      deff, ms / 1000.0, pix.size, conv, Ds, Df)
+    if world == 1 or dist is None:
+        return rows
+    import torch
+    # fixed-size exchange: every rank contributes ceil(num_images/world) rows, padded with -1
+    per = (num_images + world - 1) // world
+    buf = torch.full((per, len(COLUMNS)), -1.0, dtype=torch.float64, device=device or "cpu")
+    if len(mine):
+        buf[: len(mine)] = torch.from_numpy(rows).to(buf.device)
+    parts = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, parts, dst=0)
+    if rank != 0:
+        return None
+    table = np.zeros((num_images, len(COLUMNS)))
+    for r, part in enumerate(parts):
+        part = part.cpu().numpy()
+        for slot, k in enumerate(shard(num_images, r, world)):
+            table[k] = part[slot]
+    return table

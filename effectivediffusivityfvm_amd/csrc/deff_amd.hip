@@ -102,6 +102,9 @@ struct deff_ctx {
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
 
+    deff_progress_fn progress = nullptr;
+    void *progress_user = nullptr;
+
     int kernel = DEFF_KERNEL_AUTO;
     int rows_explicit = 0, rows_matfree = 0;     // rows per register tile, 0 = default
     int wg_matfree = 0;                          // persistent workgroups of the matrix-free kernel, 0 = default
@@ -889,6 +892,7 @@ extern "C" int deff_solve(deff_ctx *c, double omega, double tol, int64_t max_ite
             deffOld = deffNew;
             conv = change;                                           // cuh:1275
             ++checks;
+            if (c->progress) c->progress(next_check, deffNew, change, c->progress_user);   // cuh:1267-1271
         }
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -900,6 +904,14 @@ extern "C" int deff_solve(deff_ctx *c, double omega, double tol, int64_t max_ite
     out->deff_raw = deffNew;                                         // cuh:1309: value at the last check
     out->conv = conv;
     out->loop_ms = ms;
+    return DEFF_OK;
+}
+
+extern "C" int deff_set_progress(deff_ctx *c, deff_progress_fn fn, void *user)
+{
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    c->progress = fn;
+    c->progress_user = user;
     return DEFF_OK;
 }
 

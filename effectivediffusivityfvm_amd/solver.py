@@ -142,6 +142,14 @@ class Solver:
                                 MFR.ctypes.data_as(C.c_void_p)))
         return d.value, MFL, MFR
 
+    def set_progress(self, fn):
+        """fn(iter, deff_raw, change) after every convergence check, or None."""
+        if fn is None:
+            self._progress = _capi.PROGRESS_FN(0)
+        else:
+            self._progress = _capi.PROGRESS_FN(lambda it, d, ch, _u: fn(it, d, ch))
+        check(self._L.deff_set_progress(self._ctx, self._progress, None))
+
     def last_launches(self):
         """(kernel launches of the last sweeps()/solve(), sweeps per temporally blocked launch)."""
         n = C.c_int64()

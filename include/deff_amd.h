@@ -104,6 +104,11 @@ int deff_get_field(deff_ctx *ctx, double *x);                       /* final D2H
  * fluxes of the last check (cuh:1256-1257). */
 int deff_solve(deff_ctx *ctx, double omega, double tol, int64_t max_iter, int64_t check_every,
                deff_result *out, double *MFL, double *MFR);
+/* optional observer called on the host after every convergence check with
+ * (iter of the checked sweep, Deff, signed change): what the reference prints under
+ * Verbose (cuh:1267-1271).  NULL removes it. */
+typedef void (*deff_progress_fn)(int64_t iter, double deff_raw, double change, void *user);
+int deff_set_progress(deff_ctx *ctx, deff_progress_fn fn, void *user);
 /* building blocks, also used by bench.py: n sweeps without a check (ms = hipEvent
  * time on the context's stream), and one flux / Deff evaluation (cuh:1252-1263) */
 int deff_sweeps(deff_ctx *ctx, int64_t n, double omega, float *ms);

@@ -25,13 +25,16 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))[0]
+    def newest(pattern):
+        return max(glob.glob(pattern), key=os.path.getmtime)
+
+    stats = newest(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))
     shutil.copy(stats, os.path.join(dst, f"{rnd}_{tag}_kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats)))
     sweep = max(rows, key=lambda r: float(r["TotalDurationNs"]))
     pmc = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        f = glob.glob(os.path.join(src, f"pmc_{ctr}", "*", "*_counter_collection.csv"))[0]
+        f = newest(os.path.join(src, f"pmc_{ctr}", "*", "*_counter_collection.csv"))
         per = {}
         for r in csv.DictReader(open(f)):
             per.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
