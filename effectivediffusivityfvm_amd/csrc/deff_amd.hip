@@ -545,7 +545,7 @@ extern "C" int deff_get_system(deff_ctx *c, double *A, double *b)
         for (int i = 0; i < c->ny; ++i)
             for (int j = 0; j < c->nx; ++j) {
                 const size_t p = (size_t)i * c->nx + j;
-                const int idx = (pos_class(i, c->ny) * 3 + pos_class(j, c->nx)) * LUT_CODES + (code[p] & 31);
+                const int idx = (pos_class(i, c->ny) * 3 + pos_class(j, c->nx)) * LUT_CODES + ((code[p] >> 3) & 31);
                 A[p * 5 + 0] = c->lut_a0[idx];
                 for (int k = 1; k < 5; ++k) A[p * 5 + k] = c->lut_host[k * LUT_PLANE_STRIDE + idx];
                 b[p] = c->lut_host[5 * LUT_PLANE_STRIDE + idx];
@@ -610,7 +610,7 @@ struct SweepPlan {
     double omw = 0;
     int rows = 0, gx = 0, gy = 0, blocks = 0;       // single-sweep kernels
     // temporally blocked kernel
-    int T = 0, LY = 0, ntx = 0, tgx = 0, tgy = 0, tblocks = 0;
+    int T = 0, CPL = 2, LY = 0, ntx = 0, tgx = 0, tgy = 0, tblocks = 0;
     bool guard = false;
     // the reference's non-zero link test matters only when a phase cannot diffuse
     static bool guard_probe(const deff_ctx *c)
@@ -620,23 +620,34 @@ struct SweepPlan {
 };
 
 // Workgroups of the temporally blocked kernel that are resident at once on this device.
-template <int T, bool G>
+template <int T, int CPL, bool G>
 static int tb_occ(int *per_cu)
 {
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_sweep_matfree_tb<T, G>, 256, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_sweep_matfree_tb<T, CPL, G>, 256, 0));
     return DEFF_OK;
 }
 
-static int tb_resident_blocks(const deff_ctx *c, int T, bool guard, int *resident)
+// Only 2 cells per lane are instantiated: 4 per lane (twice the work per wave, 244 VGPRs,
+// 2 waves per SIMD) measured 20 % slower at 4096^2 -- the kernel needs the wave-level
+// parallelism more than it needs the smaller strip overlap.
+#define TB_DISPATCH(T_, CPL_, G_, CALL)                                                     \
+    do {                                                                                    \
+        const int key_ = (T_) * 10 + ((G_) ? 1 : 0);                                        \
+        switch (key_) {                                                                     \
+        case 20: { CALL(2, 2, false); } break; case 21: { CALL(2, 2, true); } break;       \
+        case 40: { CALL(4, 2, false); } break; case 41: { CALL(4, 2, true); } break;       \
+        case 60: { CALL(6, 2, false); } break; case 61: { CALL(6, 2, true); } break;       \
+        default: { CALL(8, 2, false); } break; case 81: { CALL(8, 2, true); } break;       \
+        }                                                                                   \
+    } while (0)
+
+static int tb_resident_blocks(const deff_ctx *c, int T, int CPL, bool guard, int *resident)
 {
     int per_cu = 0, cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-    switch (T) {
-    case 2: TRY(guard ? (tb_occ<2, true>(&per_cu)) : (tb_occ<2, false>(&per_cu))); break;
-    case 4: TRY(guard ? (tb_occ<4, true>(&per_cu)) : (tb_occ<4, false>(&per_cu))); break;
-    case 6: TRY(guard ? (tb_occ<6, true>(&per_cu)) : (tb_occ<6, false>(&per_cu))); break;
-    default: TRY(guard ? (tb_occ<8, true>(&per_cu)) : (tb_occ<8, false>(&per_cu))); break;
-    }
+#define OCC_CALL(T_, C_, G_) TRY((tb_occ<T_, C_, G_>(&per_cu)))
+    TB_DISPATCH(T, CPL, guard, OCC_CALL);
+#undef OCC_CALL
     if (per_cu < 1) per_cu = 1;
     *resident = per_cu * cus;
     return DEFF_OK;
@@ -668,13 +679,15 @@ static int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             int T = c->tb_T ? c->tb_T : 4;
             T = T >= 8 ? 8 : T >= 6 ? 6 : T >= 4 ? 4 : 2;
             pl->T = T;
-            pl->ntx = (c->nx + (TB_COLS - 2 * T) - 1) / (TB_COLS - 2 * T);
+            pl->CPL = 2;
+            const int wout = 64 * pl->CPL - 2 * T;
+            pl->ntx = (c->nx + wout - 1) / wout;
             pl->tgx = (pl->ntx + 3) / 4;
             // Rows per chunk.  Workgroups are persistent and tiles cost the same, so the
             // pass takes rounds x (LY + 2T) row steps, where one round is as many block
             // tiles as are resident at once.  Pick the (rounds, LY) pair minimising that.
             int resident = c->tb_wg;
-            if (!resident) TRY(tb_resident_blocks(c, T, SweepPlan::guard_probe(c), &resident));
+            if (!resident) TRY(tb_resident_blocks(c, T, pl->CPL, SweepPlan::guard_probe(c), &resident));
             int LY = c->tb_LY;
             if (!LY) {
                 long best_cost = -1;
@@ -783,24 +796,10 @@ static inline void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl)
     const double *xin = c->x[c->cur];
     double *xout = c->x[c->cur ^ 1];
     const int flip = c->serpentine ? c->cur : 0;
-#define LAUNCH_TB(T_, G_)                                                                                      \
-    hipLaunchKernelGGL((k_sweep_matfree_tb<T_, G_>), dim3(pl.tblocks), dim3(256), 0, c->stream, c->lut_tb,     \
+#define LAUNCH_TB(T_, C_, G_)                                                                                  \
+    hipLaunchKernelGGL((k_sweep_matfree_tb<T_, C_, G_>), dim3(pl.tblocks), dim3(256), 0, c->stream, c->lut_tb, \
                        c->code, xin, xout, c->nx, c->ny, pl.LY, pl.ntx, pl.tgx, pl.tgy, flip, pl.omw)
-    if (pl.guard) {
-        switch (pl.T) {
-        case 2: LAUNCH_TB(2, true); break;
-        case 4: LAUNCH_TB(4, true); break;
-        case 6: LAUNCH_TB(6, true); break;
-        default: LAUNCH_TB(8, true); break;
-        }
-    } else {
-        switch (pl.T) {
-        case 2: LAUNCH_TB(2, false); break;
-        case 4: LAUNCH_TB(4, false); break;
-        case 6: LAUNCH_TB(6, false); break;
-        default: LAUNCH_TB(8, false); break;
-        }
-    }
+    TB_DISPATCH(pl.T, pl.CPL, pl.guard, LAUNCH_TB);
 #undef LAUNCH_TB
     c->cur ^= 1;
 }

@@ -69,9 +69,10 @@ __global__ void k_wall_D_from_D(const double *__restrict__ D, int nx, int ny,
     Dr[i] = D[(size_t)(i + 1) * nx - 1];
 }
 
-// Matrix-free phase code, one byte per cell: bit0 own phase (1 = solid, i.e.
-// pixel >= 150), bit1 W, bit2 E, bit3 S (row+1), bit4 N (row-1) neighbour
-// phases.  Neighbours outside the mesh read the clamped cell; their bits are
+// Matrix-free phase code, one byte per cell, stored pre-scaled by 8 (= the byte
+// offset of the cell's entry inside a 32-entry x 8-B table group): bit3 own phase
+// (1 = solid, i.e. pixel >= 150), bit4 W, bit5 E, bit6 S (row+1), bit7 N (row-1)
+// neighbour phases.  Neighbours outside the mesh read the clamped cell; their bits are
 // never used because the lookup tables are selected by position class.
 __global__ void k_phase_codes(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
                               int nx, int ny, uint8_t *__restrict__ code)
@@ -87,7 +88,7 @@ __global__ void k_phase_codes(const uint8_t *__restrict__ pix, int W, int ampX, 
         c |= (cell_pixel(pix, W, ampX, ampY, i, je) >= 150) ? 4u : 0u;
         c |= (cell_pixel(pix, W, ampX, ampY, is, j) >= 150) ? 8u : 0u;
         c |= (cell_pixel(pix, W, ampX, ampY, in, j) >= 150) ? 16u : 0u;
-        code[p] = (uint8_t)c;
+        code[p] = (uint8_t)(c << 3);
     }
 }
 

@@ -244,8 +244,8 @@ __global__ __launch_bounds__(256) void k_sweep_matfree(const double *__restrict_
                 if (r >= ny) break;
                 const size_t p = p0 + (size_t)q * nx;
                 const int ycls = (r == 0) ? 1 : (r == ny - 1 ? 2 : 0);
-                const int i0 = (ycls * 3 + xcls0) * LUT_CODES + (int)(cc[q] & 31u);
-                const int i1 = (ycls * 3 + xcls1) * LUT_CODES + (int)((cc[q] >> 8) & 31u);
+                const int i0 = (ycls * 3 + xcls0) * LUT_CODES + (int)((cc[q] >> 3) & 31u);
+                const int i1 = (ycls * 3 + xcls1) * LUT_CODES + (int)((cc[q] >> 11) & 31u);
                 const double2 xm = xr[q], xc = xr[q + 1], xp = xr[q + 2];
                 double2 o;
                 o.x = jacobi_cell_lut(lut, i0, xc.x, xw[q], xc.y, xp.x, xm.x, omw);
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_sweep_matfree(const double *__restrict_
                 if (r >= ny) break;
                 const size_t p = p0 + (size_t)q * nx;
                 const int ycls = (r == 0) ? 1 : (r == ny - 1 ? 2 : 0);
-                const int i0 = (ycls * 3 + xcls) * LUT_CODES + (int)(cc[q] & 31u);
+                const int i0 = (ycls * 3 + xcls) * LUT_CODES + (int)((cc[q] >> 3) & 31u);
                 xnew[p] = jacobi_cell_lut(lut, i0, xr[q + 1], xw[q], xe[q], xr[q + 2], xr[q], omw);
             }
         }

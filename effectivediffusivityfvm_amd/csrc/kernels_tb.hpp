@@ -41,42 +41,51 @@ namespace deff {
 constexpr int TB_CLASSES = 16;
 constexpr int TB_PLANE_STRIDE = TB_CLASSES * LUT_CODES + 8;    // 520 doubles
 constexpr int TB_LUT_DOUBLES = LUT_PLANES * TB_PLANE_STRIDE;   // 3120 doubles = 24.4 KiB
-constexpr int TB_COLS = 128;                                // columns per wave strip
 
 // lane i <- lane i-1 (lane 0 <- 0.0)
 __device__ __forceinline__ double from_lane_below(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);   // bound_ctrl: lane 0 <- 0
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 // lane i <- lane i+1 (lane 63 <- 0.0)
 __device__ __forceinline__ double from_lane_above(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
-// One cell.  GUARD = reference's non-zero test on every link (needed when a
-// phase has zero diffusivity: links are -0.0 and neighbours may hold NaN/Inf,
-// cuh:77).  Without it a zero link multiplies a finite value and adds +-0,
-// which leaves sigma unchanged, so both forms give the same bits.
-template <bool GUARD>
-__device__ __forceinline__ double tb_cell(const double *lut, int idx, double xc, double xw, double xe,
+// One cell.  `off` is the BYTE offset of the cell's entry in plane 0 (position
+// class group + pre-scaled phase code); the other planes sit at fixed strides.
+// GUARD = reference's non-zero test on every link (needed when a phase has zero
+// diffusivity: links are -0.0 and neighbours may hold NaN/Inf, cuh:77).  Without
+// it a zero link multiplies a finite value and adds +-0, which leaves sigma
+// unchanged, so both forms give the same bits.  WALL = the strip contains the
+// first or last column; everywhere else b is identically +0.0 and its lookup is
+// skipped (0.0 - sigma is still evaluated as a subtraction, so the bits match).
+template <bool GUARD, bool WALL>
+__device__ __forceinline__ double tb_cell(const double *lut, unsigned off, double xc, double xw, double xe,
                                           double xs, double xn, double omw)
 {
-    const double c0 = lut[idx];
-    const double aW = lut[idx + TB_PLANE_STRIDE], aE = lut[idx + 2 * TB_PLANE_STRIDE];
-    const double aS = lut[idx + 3 * TB_PLANE_STRIDE], aN = lut[idx + 4 * TB_PLANE_STRIDE];
-    const double b = lut[idx + 5 * TB_PLANE_STRIDE];
+    const char *base = reinterpret_cast<const char *>(lut) + off;
+    constexpr int PS = TB_PLANE_STRIDE * 8;
+    const double c0 = *reinterpret_cast<const double *>(base);
+    const double aW = *reinterpret_cast<const double *>(base + PS);
+    const double aE = *reinterpret_cast<const double *>(base + 2 * PS);
+    const double aS = *reinterpret_cast<const double *>(base + 3 * PS);
+    const double aN = *reinterpret_cast<const double *>(base + 4 * PS);
+    double b = 0.0;
+    if constexpr (WALL) b = *reinterpret_cast<const double *>(base + 5 * PS);
     if constexpr (GUARD) {
         return jacobi_cell(c0, aW, aE, aS, aN, b, xc, xw, xe, xs, xn, omw);
     } else {
-        double sigma = 0;
-        sigma += aW * xw;
+        // the reference starts from sigma = 0 (cuh:74); 0 + p differs from p only in the sign of a
+        // zero, which b - sigma cannot see (b is +0 or non-zero), so the leading add is dropped
+        double sigma = aW * xw;
         sigma += aE * xe;
         sigma += aS * xs;
         sigma += aN * xn;
@@ -89,9 +98,122 @@ __device__ __forceinline__ int tb_ycls(int r, int ny)
     return (r < 0 || r >= ny) ? 3 : (r == 0 ? 1 : (r == ny - 1 ? 2 : 0));
 }
 
+// One strip x chunk: the whole row pipeline of a wave.  CPL = cells per lane: the
+// strip is 64*CPL columns wide and produces 64*CPL - 2T valid columns.  Written for
+// any even CPL; only CPL = 2 is instantiated (4 was measured slower, see deff_amd.hip).
+template <int T, int CPL, bool GUARD, bool WALL>
+__device__ __forceinline__ void tb_strip(const double *lut, const uint8_t *__restrict__ code,
+                                         const double *__restrict__ x, double *__restrict__ xnew, int nx,
+                                         int ny, int tx, int ry0, int LY, int lane, double omw)
+{
+    constexpr int NP = CPL / 2;                    // 16-B pairs per lane
+    constexpr int WOUT = 64 * CPL - 2 * T;
+    const int cx0 = tx * WOUT;                     // first output column of the strip
+    const int col = cx0 - T + CPL * lane;          // this lane's first column (even)
+    const int ry1 = min(ry0 + LY, ny);
+    const int r_begin = ry0 - T, r_end = ry1 + T;  // input rows [r_begin, r_end)
+    bool in_x[NP], st_x[NP];
+    unsigned xoff[CPL];                            // byte offset of each cell's x position class group
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int c = col + 2 * q;
+        in_x[q] = (c >= 0) && (c < nx);            // nx even => c+1 < nx too
+        st_x[q] = in_x[q] && (c >= cx0) && (c < cx0 + WOUT);
+        xoff[2 * q] = (unsigned)(!in_x[q] ? 3 : (c == 0 ? 1 : 0)) * (LUT_CODES * 8);
+        xoff[2 * q + 1] = (unsigned)(!in_x[q] ? 3 : (c + 1 == nx - 1 ? 2 : 0)) * (LUT_CODES * 8);
+    }
+    const double2 zero = make_double2(0.0, 0.0);
+
+    double w[T][3][CPL];                           // w[t][slot]: 3 newest rows of sweep t
+    unsigned cw[T + 1][NP];                        // cw[t]: codes of row rr-t (2 per 16-bit pair)
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) w[t][sl][q] = 0.0;
+#pragma unroll
+    for (int t = 0; t <= T; ++t)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) cw[t][q] = 0u;
+
+    double2 nx_x[3][NP];
+    unsigned nx_c[3][NP];
+    auto fetch = [&](int rr, double2 *vx, unsigned *vc) {
+        const bool row_ok = rr >= 0 && rr < ny && rr < r_end;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const bool ok = row_ok && in_x[q];
+            const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col + 2 * q : 0);
+            vx[q] = ok ? ld2(x + p) : zero;
+            vc[q] = ok ? (unsigned)*reinterpret_cast<const uint16_t *>(code + p) : 0u;
+        }
+    };
+    // prefetch the first group of three rows
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fetch(r_begin + k, nx_x[k], nx_c[k]);
+
+    // (A skewed variant -- sweep t working from the previous step's rows so that the T updates
+    // of a step are independent -- was measured: hipcc hoists every lookup, 198 VGPRs at T = 4,
+    // 2 waves per SIMD, no faster; constrained to 128 VGPRs it spills.  Not kept.)
+    for (int r = r_begin; r < r_end; r += 3) {
+        double2 cur_x[3][NP];
+        unsigned cur_c[3][NP];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) { cur_x[k][q] = nx_x[k][q]; cur_c[k][q] = nx_c[k][q]; }
+        // issue the next group's loads before working on this one
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fetch(r + 3 + k, nx_x[k], nx_c[k]);
+#pragma unroll
+        for (int ph = 0; ph < 3; ++ph) {
+            const int rr = r + ph;                 // input row of this step
+            // after this step's level-(t-1) write: newest = slot ph, previous = (ph+2)%3, oldest = (ph+1)%3
+            const int sN = (ph + 1) % 3, sC = (ph + 2) % 3, sS = ph;
+#pragma unroll
+            for (int t = T; t >= 1; --t)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) cw[t][q] = cw[t - 1][q];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                cw[0][q] = cur_c[ph][q];
+                w[0][sS][2 * q] = cur_x[ph][q].x;
+                w[0][sS][2 * q + 1] = cur_x[ph][q].y;
+            }
+#pragma unroll
+            for (int t = 1; t <= T; ++t) {
+                const int rt = rr - t;             // row produced by sweep t in this step
+                const double *vN = w[t - 1][sN], *vC = w[t - 1][sC], *vS = w[t - 1][sS];
+                const double xw_first = from_lane_below(vC[CPL - 1]);
+                const double xe_last = from_lane_above(vC[0]);
+                // byte offset = class group (multiple of 256) | pre-scaled code (< 256)
+                const unsigned ybase = (unsigned)tb_ycls(rt, ny) * (4 * LUT_CODES * 8);
+                double o[CPL];
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    const unsigned cbits = (q & 1) ? (cw[t][q >> 1] >> 8) : cw[t][q >> 1];
+                    const unsigned off = (cbits & 0xF8u) | (ybase + xoff[q]);
+                    const double xw = (q == 0) ? xw_first : vC[q - 1];
+                    const double xe = (q == CPL - 1) ? xe_last : vC[q + 1];
+                    o[q] = tb_cell<GUARD, WALL>(lut, off, vC[q], xw, xe, vS[q], vN[q], omw);
+                }
+                if (t < T) {
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) w[t][sS][q] = o[q];
+                } else if (rt >= ry0 && rt < ry1) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        if (st_x[q]) st2(xnew + (size_t)rt * nx + col + 2 * q, make_double2(o[2 * q], o[2 * q + 1]));
+                }
+            }
+        }
+    }
+}
+
 // grid: persistent workgroups of 4 waves; wave w of block-tile (btx, bty) owns
 // strip tx = btx*4 + w and rows [bty*LY, bty*LY + LY).  nx must be even, T even.
-template <int T, bool GUARD>
+template <int T, int CPL, bool GUARD>
 __global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restrict__ lut_g,
                                                           const uint8_t *__restrict__ code,
                                                           const double *__restrict__ x,
@@ -99,12 +221,11 @@ __global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restri
                                                           int LY, int ntx, int gx, int gy, int flip,
                                                           double omw)
 {
-    static_assert(T >= 1 && T <= 8, "T out of range");
+    static_assert(T >= 1 && T <= 8 && (CPL == 2 || CPL == 4), "unsupported T / CPL");
     __shared__ double lut[TB_LUT_DOUBLES];
     for (int k = threadIdx.x; k < TB_LUT_DOUBLES; k += 256) lut[k] = lut_g[k];
     __syncthreads();
 
-    constexpr int WOUT = TB_COLS - 2 * T;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const unsigned total = (unsigned)gx * (unsigned)gy;
@@ -119,80 +240,10 @@ __global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restri
         const int tx = btx * 4 + wave;
         if (tx >= ntx) continue;                       // wave-uniform
 
-        const int cx0 = tx * WOUT;                     // first output column of the strip
-        const int col = cx0 - T + 2 * lane;            // this lane's first column (even)
-        const bool in_x = (col >= 0) && (col < nx);    // nx even => col+1 < nx too
-        const int ry0 = bty * LY;
-        const int ry1 = min(ry0 + LY, ny);
-        const int r_begin = ry0 - T, r_end = ry1 + T;  // input rows [r_begin, r_end)
-        const bool st_x = in_x && (col >= cx0) && (col < cx0 + WOUT);
-        // x position classes of the two cells (3 = outside the mesh)
-        const int xoff0 = (!in_x ? 3 : (col == 0 ? 1 : 0)) * LUT_CODES;
-        const int xoff1 = (!in_x ? 3 : (col + 1 == nx - 1 ? 2 : 0)) * LUT_CODES;
-        const double2 zero = make_double2(0.0, 0.0);
-
-        double2 w[T][3];                               // w[t]: 3 newest rows of sweep t
-        unsigned cw[T + 1];                            // cw[t]: codes of row r-t
-#pragma unroll
-        for (int t = 0; t < T; ++t) { w[t][0] = zero; w[t][1] = zero; w[t][2] = zero; }
-#pragma unroll
-        for (int t = 0; t <= T; ++t) cw[t] = 0u;
-
-        // prefetch the first group of three rows
-        double2 nx_x[3];
-        unsigned nx_c[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int rr = r_begin + k;
-            const bool ok = in_x && rr >= 0 && rr < ny && rr < r_end;
-            const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col : 0);
-            nx_x[k] = ok ? ld2(x + p) : zero;
-            nx_c[k] = ok ? (unsigned)*reinterpret_cast<const uint16_t *>(code + p) : 0u;
-        }
-
-        for (int r = r_begin; r < r_end; r += 3) {
-            double2 cur_x[3];
-            unsigned cur_c[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { cur_x[k] = nx_x[k]; cur_c[k] = nx_c[k]; }
-            // issue the next group's loads before working on this one
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int rr = r + 3 + k;
-                const bool ok = in_x && rr >= 0 && rr < ny && rr < r_end;
-                const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col : 0);
-                nx_x[k] = ok ? ld2(x + p) : zero;
-                nx_c[k] = ok ? (unsigned)*reinterpret_cast<const uint16_t *>(code + p) : 0u;
-            }
-#pragma unroll
-            for (int ph = 0; ph < 3; ++ph) {
-                const int rr = r + ph;                 // input row of this step
-                // slots: newest = ph, previous = (ph+2)%3, oldest = (ph+1)%3
-                const int sN = (ph + 1) % 3, sC = (ph + 2) % 3, sS = ph;
-#pragma unroll
-                for (int t = T; t >= 1; --t) cw[t] = cw[t - 1];
-                cw[0] = cur_c[ph];
-                w[0][sS] = cur_x[ph];
-#pragma unroll
-                for (int t = 1; t <= T; ++t) {
-                    const int rt = rr - t;             // row produced by sweep t in this step
-                    const double2 vN = w[t - 1][sN], vC = w[t - 1][sC], vS = w[t - 1][sS];
-                    const double xw0 = from_lane_below(vC.y);
-                    const double xe1 = from_lane_above(vC.x);
-                    const int ybase = tb_ycls(rt, ny) * 4 * LUT_CODES;
-                    const int i0 = ybase + xoff0 + (int)(cw[t] & 31u);
-                    const int i1 = ybase + xoff1 + (int)((cw[t] >> 8) & 31u);
-                    double2 o;
-                    o.x = tb_cell<GUARD>(lut, i0, vC.x, xw0, vC.y, vS.x, vN.x, omw);
-                    o.y = tb_cell<GUARD>(lut, i1, vC.y, vC.x, xe1, vS.y, vN.y, omw);
-                    if (t < T) {
-                        w[t][sS] = o;
-                    } else if (st_x && rt >= ry0 && rt < ry1) {
-                        st2(xnew + (size_t)rt * nx + col, o);
-                    }
-                }
-            }
-        }
+        if (tx == 0 || tx == ntx - 1)
+            tb_strip<T, CPL, GUARD, true>(lut, code, x, xnew, nx, ny, tx, bty * LY, LY, lane, omw);
+        else
+            tb_strip<T, CPL, GUARD, false>(lut, code, x, xnew, nx, ny, tx, bty * LY, LY, lane, omw);
     }
 }
 

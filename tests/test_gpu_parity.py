@@ -142,7 +142,7 @@ def test_sweeps_ragged_shapes_vs_oracle(pkg, oracle, shape, kernel):
 
 @pytest.mark.parametrize("T", [2, 4, 6, 8])
 @pytest.mark.parametrize("shape,LY", [((600, 300), 0), ((600, 300), 7), ((1030, 37), 16), ((130, 70), 5),
-                                      ((256, 256), 64), ((122, 9), 0), ((2, 64), 0)])
+                                      ((256, 256), 64), ((122, 9), 0), ((2, 64), 0), ((498, 40), 0), ((250, 33), 11)])
 def test_temporal_blocking_vs_oracle(pkg, oracle, shape, LY, T):
     """T sweeps per pass, strips and chunks of every raggedness, sweep counts that are
     not multiples of T (the remainder runs on the single-sweep kernel)."""
