@@ -17,10 +17,10 @@ KERNEL_NAMES = {"auto": 0, "explicit": 1, "scalar": 2, "matfree": 3, "matfree_tb
 # every symbol include/deff_amd.h declares (tests check the library exports them all)
 SYMBOLS = [
     "deff_version", "deff_last_error", "deff_error_string", "deff_device_count",
-    "deff_create", "deff_destroy", "deff_mesh", "deff_set_kernel", "deff_get_kernel",
+    "deff_create", "deff_create_batch", "deff_batch_size", "deff_destroy", "deff_mesh", "deff_set_kernel", "deff_get_kernel",
     "deff_set_tuning", "deff_set_image", "deff_synth_image", "deff_get_image",
     "deff_assemble_2phase", "deff_assemble_from_D", "deff_set_system", "deff_get_system",
-    "deff_init_linear", "deff_set_field", "deff_get_field", "deff_solve", "deff_sweeps",
+    "deff_init_linear", "deff_set_field", "deff_get_field", "deff_solve", "deff_solve_batch", "deff_sweeps",
     "deff_flux", "deff_set_progress", "deff_last_launches", "deff_device_field", "deff_synchronize",
 ]
 
@@ -59,6 +59,8 @@ def load():
     L.deff_error_string.argtypes = [C.c_int]
     L.deff_device_count.argtypes = [C.POINTER(C.c_int)]
     L.deff_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(ctx)]
+    L.deff_create_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ctx)]
+    L.deff_batch_size.argtypes = [ctx, C.POINTER(C.c_int)]
     L.deff_destroy.argtypes = [ctx]
     L.deff_mesh.argtypes = [ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
                             C.POINTER(C.c_double)]
@@ -77,6 +79,8 @@ def load():
     L.deff_get_field.argtypes = [ctx, _dp]
     L.deff_solve.argtypes = [ctx, C.c_double, C.c_double, C.c_int64, C.c_int64, C.POINTER(Result),
                              C.c_void_p, C.c_void_p]
+    L.deff_solve_batch.argtypes = [ctx, C.c_double, C.c_double, C.c_int64, C.c_int64, C.POINTER(Result),
+                                   C.c_void_p, C.c_void_p]
     L.deff_sweeps.argtypes = [ctx, C.c_int64, C.c_double, C.POINTER(C.c_float)]
     L.deff_flux.argtypes = [ctx, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
     L.deff_set_progress.argtypes = [ctx, PROGRESS_FN, C.c_void_p]

@@ -59,8 +59,11 @@ static int fail(int code, const char *fmt, ...)
 
 struct deff_ctx {
     int device = 0;
-    int nx = 0, ny = 0;
-    size_t n = 0;
+    int nx = 0, ny = 0;             // mesh of ONE image
+    int nimg = 1;                   // images stacked in this context (batch), see kernels_setup.hpp
+    int rows = 0;                   // nimg * ny
+    size_t n_img = 0;               // cells per image
+    size_t n = 0;                   // cells in the stack
     double dx = 0, dy = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -97,6 +100,11 @@ struct deff_ctx {
     double *x[2] = {nullptr, nullptr};
     int cur = 0;
     bool have_field = false;
+    // batch bookkeeping: images still iterating (device mask is only bound while some are
+    // frozen) and, per image, the ping-pong buffer that holds its newest field
+    uint8_t *active = nullptr;
+    std::vector<uint8_t> active_h, buf_of;
+    bool masked = false;
 
     // scratch for chunked uploads (AoS import, D upload)
     void *scratch = nullptr;
@@ -111,6 +119,7 @@ struct deff_ctx {
     int nt_explicit = 1;                         // non-temporal coefficient loads in the explicit kernels
     int serpentine = 1;                          // alternate the tile walk direction from sweep to sweep
     int tb_T = 0, tb_LY = 0, tb_wg = 0;          // temporal blocking: sweeps per pass, rows per chunk, workgroups
+    int tb_xmajor = 1;                           // wave-tile numbering of the temporally blocked kernel
     int64_t last_launches = 0;                   // sweep-kernel launches of the last deff_sweeps()/deff_solve()
 };
 
@@ -148,10 +157,10 @@ static int ensure_explicit(deff_ctx *c)
 
 static int ensure_walls(deff_ctx *c)
 {
-    TRY(dev_alloc(&c->Dl, (size_t)c->ny));
-    TRY(dev_alloc(&c->Dr, (size_t)c->ny));
-    TRY(dev_alloc(&c->mf, (size_t)2 * c->ny));
-    if (!c->mf_host) HIP_TRY(hipHostMalloc((void **)&c->mf_host, sizeof(double) * 2 * c->ny));
+    TRY(dev_alloc(&c->Dl, (size_t)c->rows));
+    TRY(dev_alloc(&c->Dr, (size_t)c->rows));
+    TRY(dev_alloc(&c->mf, (size_t)2 * c->rows));
+    if (!c->mf_host) HIP_TRY(hipHostMalloc((void **)&c->mf_host, sizeof(double) * 2 * c->rows));
     return DEFF_OK;
 }
 
@@ -195,11 +204,17 @@ extern "C" int deff_device_count(int *count)
 
 extern "C" int deff_create(int device, int nx, int ny, deff_ctx **out)
 {
+    return deff_create_batch(device, nx, ny, 1, out);
+}
+
+extern "C" int deff_create_batch(int device, int nx, int ny, int nimg, deff_ctx **out)
+{
     if (!out) return fail(DEFF_EINVAL, "out is NULL");
     *out = nullptr;
     if (nx < 2 || ny < 2) return fail(DEFF_EINVAL, "mesh must be at least 2x2 (got %dx%d)", nx, ny);
-    if ((size_t)nx * (size_t)ny > (size_t)1 << 31)
-        return fail(DEFF_EINVAL, "mesh %dx%d exceeds 2^31 cells", nx, ny);
+    if (nimg < 1) return fail(DEFF_EINVAL, "batch size must be >= 1 (got %d)", nimg);
+    if ((size_t)nx * (size_t)ny * (size_t)nimg > (size_t)1 << 31 || (long long)ny * nimg > (1ll << 30))
+        return fail(DEFF_EINVAL, "%d image(s) of %dx%d exceed 2^31 cells", nimg, nx, ny);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -209,7 +224,9 @@ extern "C" int deff_create(int device, int nx, int ny, deff_ctx **out)
     deff_ctx *c = new (std::nothrow) deff_ctx();
     if (!c) return fail(DEFF_ENOMEM, "host allocation failed");
     c->device = device;
-    c->nx = nx; c->ny = ny; c->n = (size_t)nx * ny;
+    c->nx = nx; c->ny = ny; c->nimg = nimg; c->rows = nimg * ny;
+    c->n_img = (size_t)nx * ny; c->n = c->n_img * nimg;
+    c->active_h.assign(nimg, 1); c->buf_of.assign(nimg, 0);
     c->dx = 1.0 / nx;           // cuh:1910-1911: the domain is always the unit square
     c->dy = 1.0 / ny;
     int rc = DEFF_OK;
@@ -241,7 +258,7 @@ extern "C" int deff_destroy(deff_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->pix, c->a0, c->c0, c->aW, c->aE, c->aS, c->aN, c->b, c->code, c->lut, c->lut_tb,
-                    c->Dl, c->Dr, c->mf, c->x[0], c->x[1], c->scratch};
+                    c->Dl, c->Dr, c->mf, c->x[0], c->x[1], c->scratch, c->active};
     for (void *p : bufs) if (p) (void)hipFree(p);
     if (c->mf_host) (void)hipHostFree(c->mf_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -259,6 +276,21 @@ extern "C" int deff_mesh(const deff_ctx *c, int *nx, int *ny, double *dx, double
     if (dx) *dx = c->dx;
     if (dy) *dy = c->dy;
     return DEFF_OK;
+}
+
+extern "C" int deff_batch_size(const deff_ctx *c, int *nimg)
+{
+    if (!c || !nimg) return fail(DEFF_EINVAL, "NULL argument");
+    *nimg = c->nimg;
+    return DEFF_OK;
+}
+
+// All images iterate again and their newest field is in x[cur] (after a new guess / system).
+static void reset_batch_state(deff_ctx *c)
+{
+    c->active_h.assign(c->nimg, 1);
+    c->buf_of.assign(c->nimg, (uint8_t)c->cur);
+    c->masked = false;
 }
 
 extern "C" int deff_set_kernel(deff_ctx *c, int kernel)
@@ -304,6 +336,7 @@ extern "C" int deff_set_tuning(deff_ctx *c, const char *key, int value)
     else if (!strcmp(key, "serpentine")) c->serpentine = value ? 1 : 0;
     else if (!strcmp(key, "tb_T")) c->tb_T = value;
     else if (!strcmp(key, "tb_LY")) c->tb_LY = value;
+    else if (!strcmp(key, "tb_xmajor")) c->tb_xmajor = value ? 1 : 0;
     else if (!strcmp(key, "tb_wg")) c->tb_wg = (value + 7) / 8 * 8;
     else return fail(DEFF_EINVAL, "unknown tuning key '%s'", key);
     return DEFF_OK;
@@ -319,7 +352,7 @@ static int image_shape(deff_ctx *c, int W, int H, int ampX, int ampY)
         return fail(DEFF_EINVAL, "image %dx%d x amp %dx%d does not match mesh %dx%d", W, H, ampX, ampY,
                     c->nx, c->ny);
     if (c->pix && (c->W != W || c->H != H)) { HIP_TRY(hipFree(c->pix)); c->pix = nullptr; }
-    TRY(dev_alloc(&c->pix, (size_t)W * H));
+    TRY(dev_alloc(&c->pix, (size_t)W * H * c->nimg));
     c->W = W; c->H = H; c->ampX = ampX; c->ampY = ampY;
     return DEFF_OK;
 }
@@ -329,7 +362,7 @@ extern "C" int deff_set_image(deff_ctx *c, const uint8_t *pix, int W, int H, int
     if (!c || !pix) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
     TRY(image_shape(c, W, H, ampX, ampY));
-    HIP_TRY(hipMemcpyAsync(c->pix, pix, (size_t)W * H, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->pix, pix, (size_t)W * H * c->nimg, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_image = true;
     c->have_matfree = false;
@@ -341,7 +374,8 @@ extern "C" int deff_synth_image(deff_ctx *c, uint64_t seed, uint64_t img)
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     TRY(use_device(c));
     TRY(image_shape(c, c->nx, c->ny, 1, 1));
-    hipLaunchKernelGGL(k_synth_mask, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->nx, c->ny,
+    // stacked rows continue the per-pixel key, so a batch holds images img, img+1, ...
+    hipLaunchKernelGGL(k_synth_mask, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->nx, c->rows,
                        seed, img);
     HIP_TRY(hipGetLastError());
     c->have_image = true;
@@ -354,7 +388,7 @@ extern "C" int deff_get_image(deff_ctx *c, uint8_t *pix)
     if (!c || !pix) return fail(DEFF_EINVAL, "NULL argument");
     if (!c->have_image) return fail(DEFF_ESTATE, "no image set");
     TRY(use_device(c));
-    HIP_TRY(hipMemcpyAsync(pix, c->pix, (size_t)c->W * c->H, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(pix, c->pix, (size_t)c->W * c->H * c->nimg, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DEFF_OK;
 }
@@ -414,15 +448,15 @@ extern "C" int deff_assemble_2phase(deff_ctx *c, double Ds, double Df, double CL
     TRY(use_device(c));
     TRY(ensure_walls(c));
     c->CL = CL; c->CR = CR;
-    hipLaunchKernelGGL(k_wall_D_2phase, dim3((c->ny + 255) / 256), dim3(256), 0, c->stream, c->pix, c->W,
-                       c->ampX, c->ampY, c->nx, c->ny, Df, Ds, c->Dl, c->Dr);
+    hipLaunchKernelGGL(k_wall_D_2phase, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, c->pix, c->W,
+                       c->ampX, c->ampY, c->nx, c->ny, c->rows, Df, Ds, c->Dl, c->Dr);
     HIP_TRY(hipGetLastError());
     c->have_walls = true;
 
     // matrix-free form: 1 byte per cell + lookup tables
     TRY(dev_alloc(&c->code, c->n));
     hipLaunchKernelGGL(k_phase_codes, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->W, c->ampX,
-                       c->ampY, c->nx, c->ny, c->code);
+                       c->ampY, c->nx, c->ny, c->rows, c->code);
     HIP_TRY(hipGetLastError());
     build_lut_rows(c, Ds, Df, CL, CR);
     c->have_matfree = true;
@@ -444,9 +478,10 @@ static int explicit_from_image(deff_ctx *c)
     TRY(ensure_scratch(c, sizeof(double) * c->n));
     double *D = (double *)c->scratch;
     hipLaunchKernelGGL(k_fill_D_2phase, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->W, c->ampX,
-                       c->ampY, c->nx, c->ny, c->Df, c->Ds, D);
+                       c->ampY, c->nx, c->ny, c->rows, c->Df, c->Ds, D);
     hipLaunchKernelGGL(k_assemble_from_D, dim3(grid_for(c->n)), dim3(256), 0, c->stream, D,
-                       (const unsigned int *)nullptr, c->nx, c->ny, c->dx, c->dy, c->CL, c->CR, soa_of(c));
+                       (const unsigned int *)nullptr, c->nx, c->ny, c->rows, c->dx, c->dy, c->CL, c->CR,
+                       soa_of(c));
     HIP_TRY(hipGetLastError());
     c->have_explicit = true;
     c->c0_omega = NAN;
@@ -471,9 +506,9 @@ extern "C" int deff_assemble_from_D(deff_ctx *c, const double *D, const unsigned
     if (Grid) HIP_TRY(hipMemcpyAsync(dG, Grid, sizeof(unsigned int) * c->n, hipMemcpyHostToDevice, c->stream));
     c->CL = CL; c->CR = CR;
     hipLaunchKernelGGL(k_assemble_from_D, dim3(grid_for(c->n)), dim3(256), 0, c->stream, dD, dG, c->nx,
-                       c->ny, c->dx, c->dy, CL, CR, soa_of(c));
-    hipLaunchKernelGGL(k_wall_D_from_D, dim3((c->ny + 255) / 256), dim3(256), 0, c->stream, dD, c->nx, c->ny,
-                       c->Dl, c->Dr);
+                       c->ny, c->rows, c->dx, c->dy, CL, CR, soa_of(c));
+    hipLaunchKernelGGL(k_wall_D_from_D, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, dD, c->nx,
+                       c->rows, c->Dl, c->Dr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_explicit = true; c->c0_omega = NAN; c->have_walls = true;
@@ -503,12 +538,12 @@ extern "C" int deff_set_system(deff_ctx *c, const double *A, const double *b, co
     if (D) {
         TRY(ensure_walls(c));
         // only the first and last column of D are ever read (cuh:1256-1257)
-        for (int i = 0; i < c->ny; ++i) {
+        for (int i = 0; i < c->rows; ++i) {
             c->mf_host[i] = D[(size_t)i * c->nx];
-            c->mf_host[c->ny + i] = D[(size_t)(i + 1) * c->nx - 1];
+            c->mf_host[c->rows + i] = D[(size_t)(i + 1) * c->nx - 1];
         }
-        HIP_TRY(hipMemcpyAsync(c->Dl, c->mf_host, sizeof(double) * c->ny, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->Dr, c->mf_host + c->ny, sizeof(double) * c->ny, hipMemcpyHostToDevice,
+        HIP_TRY(hipMemcpyAsync(c->Dl, c->mf_host, sizeof(double) * c->rows, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->Dr, c->mf_host + c->rows, sizeof(double) * c->rows, hipMemcpyHostToDevice,
                                c->stream));
         c->have_walls = true;
     }
@@ -542,10 +577,10 @@ extern "C" int deff_get_system(deff_ctx *c, double *A, double *b)
         std::vector<uint8_t> code(c->n);
         HIP_TRY(hipMemcpyAsync(code.data(), c->code, c->n, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        for (int i = 0; i < c->ny; ++i)
+        for (int i = 0; i < c->rows; ++i)
             for (int j = 0; j < c->nx; ++j) {
                 const size_t p = (size_t)i * c->nx + j;
-                const int idx = (pos_class(i, c->ny) * 3 + pos_class(j, c->nx)) * LUT_CODES + ((code[p] >> 3) & 31);
+                const int idx = (pos_class(i % c->ny, c->ny) * 3 + pos_class(j, c->nx)) * LUT_CODES + ((code[p] >> 3) & 31);
                 A[p * 5 + 0] = c->lut_a0[idx];
                 for (int k = 1; k < 5; ++k) A[p * 5 + k] = c->lut_host[k * LUT_PLANE_STRIDE + idx];
                 b[p] = c->lut_host[5 * LUT_PLANE_STRIDE + idx];
@@ -562,9 +597,27 @@ extern "C" int deff_init_linear(deff_ctx *c, double CL, double CR)
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     TRY(use_device(c));
     hipLaunchKernelGGL(k_init_linear, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->x[c->cur], c->nx,
-                       c->ny, CL, CR);
+                       c->rows, CL, CR);
     HIP_TRY(hipGetLastError());
     c->have_field = true;
+    reset_batch_state(c);
+    return DEFF_OK;
+}
+
+// After a batch solve the images that converged earlier sit frozen in whichever ping-pong
+// buffer was current at that moment; bring every image's newest field into x[cur].
+static int consolidate(deff_ctx *c)
+{
+    if (!c->masked) return DEFF_OK;                  // nothing frozen: every image is current in x[cur]
+    for (int k = 0; k < c->nimg; ++k)
+        if (c->buf_of[k] != (uint8_t)c->cur) {
+            const size_t off = (size_t)k * c->n_img;
+            HIP_TRY(hipMemcpyAsync(c->x[c->cur] + off, c->x[c->buf_of[k]] + off, sizeof(double) * c->n_img,
+                                   hipMemcpyDeviceToDevice, c->stream));
+            c->buf_of[k] = (uint8_t)c->cur;
+        }
+    c->active_h.assign(c->nimg, 1);
+    c->masked = false;
     return DEFF_OK;
 }
 
@@ -575,6 +628,7 @@ extern "C" int deff_set_field(deff_ctx *c, const double *x)
     HIP_TRY(hipMemcpyAsync(c->x[c->cur], x, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_field = true;
+    reset_batch_state(c);
     return DEFF_OK;
 }
 
@@ -582,6 +636,7 @@ extern "C" int deff_get_field(deff_ctx *c, double *x)
 {
     if (!c || !x) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
+    TRY(consolidate(c));
     HIP_TRY(hipMemcpyAsync(x, c->x[c->cur], sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DEFF_OK;
@@ -590,6 +645,8 @@ extern "C" int deff_get_field(deff_ctx *c, double *x)
 extern "C" int deff_device_field(deff_ctx *c, void **d_x, size_t *pitch)
 {
     if (!c || !d_x) return fail(DEFF_EINVAL, "NULL argument");
+    TRY(use_device(c));
+    TRY(consolidate(c));
     *d_x = c->x[c->cur];
     if (pitch) *pitch = sizeof(double) * c->nx;
     return DEFF_OK;
@@ -608,9 +665,9 @@ extern "C" int deff_synchronize(deff_ctx *c)
 struct SweepPlan {
     int kernel = 0;
     double omw = 0;
-    int rows = 0, gx = 0, gy = 0, blocks = 0;       // single-sweep kernels
+    int rows = 0, cpi = 0, gx = 0, gy = 0, blocks = 0;   // single-sweep kernels (cpi: row tiles per image)
     // temporally blocked kernel
-    int T = 0, CPL = 2, LY = 0, ntx = 0, tgx = 0, tgy = 0, tblocks = 0;
+    int T = 0, CPL = 2, LY = 0, tcpi = 0, ntx = 0, tgx = 0, tgy = 0, tblocks = 0;
     bool guard = false;
     // the reference's non-zero link test matters only when a phase cannot diffuse
     static bool guard_probe(const deff_ctx *c)
@@ -663,7 +720,8 @@ static void tile_grid(const deff_ctx *c, int cols_per_block, int rows, SweepPlan
 {
     pl->rows = rows;
     pl->gx = (c->nx + cols_per_block - 1) / cols_per_block;
-    pl->gy = (c->ny + rows - 1) / rows;
+    pl->cpi = (c->ny + rows - 1) / rows;               // row tiles never straddle two images
+    pl->gy = pl->cpi * c->nimg;
     const unsigned total = (unsigned)pl->gx * (unsigned)pl->gy;
     pl->blocks = (int)(((total + 7u) / 8u) * 8u);      // see xcd_tile()
 }
@@ -676,13 +734,14 @@ static int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
     if (pl->kernel == DEFF_KERNEL_MATFREE || pl->kernel == DEFF_KERNEL_MATFREE_TB) {
         TRY(upload_lut(c, omega));
         if (pl->kernel == DEFF_KERNEL_MATFREE_TB) {
-            int T = c->tb_T ? c->tb_T : 4;
+            // sweeps per pass: 6 once the stack is big enough to fill the chip (measured at 4096^2:
+            // T=4 919, T=6 1005, T=8 1046 G cells*iter/s; 16 x 1024^2: 879 / 966 / 932), else 4
+            int T = c->tb_T ? c->tb_T : (c->n >= ((size_t)1 << 22) ? 6 : 4);
             T = T >= 8 ? 8 : T >= 6 ? 6 : T >= 4 ? 4 : 2;
             pl->T = T;
             pl->CPL = 2;
             const int wout = 64 * pl->CPL - 2 * T;
             pl->ntx = (c->nx + wout - 1) / wout;
-            pl->tgx = (pl->ntx + 3) / 4;
             // Rows per chunk.  Workgroups are persistent and tiles cost the same, so the
             // pass takes rounds x (LY + 2T) row steps, where one round is as many block
             // tiles as are resident at once.  Pick the (rounds, LY) pair minimising that.
@@ -692,7 +751,9 @@ static int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             if (!LY) {
                 long best_cost = -1;
                 for (int k = 1; k <= 8; ++k) {
-                    const int tgy_max = (int)(((long)k * resident) / pl->tgx);
+                    // chunks per image such that nimg x ntx x chunks wave tiles fill k rounds of
+                    // `resident` workgroups (4 waves each)
+                    const int tgy_max = (int)(((long)k * resident * 4) / ((long)pl->ntx * c->nimg));
                     if (tgy_max < 1) continue;
                     int ly = (c->ny + tgy_max - 1) / tgy_max;
                     if (ly < 1) ly = 1;
@@ -703,8 +764,10 @@ static int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             }
             if (LY > c->ny) LY = c->ny;
             pl->LY = LY;
-            pl->tgy = (c->ny + LY - 1) / LY;
-            const unsigned total = (unsigned)pl->tgx * (unsigned)pl->tgy;
+            pl->tcpi = (c->ny + LY - 1) / LY;
+            pl->tgy = pl->tcpi * c->nimg;
+            pl->tgx = (int)(((long)pl->ntx * pl->tgy + 3) / 4);       // workgroup tiles (4 wave tiles each)
+            const unsigned total = (unsigned)pl->tgx;
             pl->tblocks = (int)(((total + 7u) / 8u) * 8u);
             if (pl->tblocks > resident) pl->tblocks = resident >= 8 ? resident / 8 * 8 : 8;
             // the reference's non-zero link test matters only when a phase cannot diffuse
@@ -736,24 +799,25 @@ static inline void enqueue_sweep(deff_ctx *c, const SweepPlan &pl)
     double *xout = c->x[c->cur ^ 1];
     const CoefConst cf{c->c0, c->aW, c->aE, c->aS, c->aN, c->b};
     const int flip = c->serpentine ? c->cur : 0;
+    const uint8_t *mask = c->masked ? c->active : nullptr;
     switch (pl.kernel) {
     case DEFF_KERNEL_SCALAR:
         if (c->nt_explicit)
             hipLaunchKernelGGL(k_sweep_scalar<true>, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
-                               cf, xin, xout, c->nx, c->n, pl.omw);
+                               cf, xin, xout, c->nx, c->n, c->n_img, mask, pl.omw);
         else
             hipLaunchKernelGGL(k_sweep_scalar<false>, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
-                               cf, xin, xout, c->nx, c->n, pl.omw);
+                               cf, xin, xout, c->nx, c->n, c->n_img, mask, pl.omw);
         break;
     case DEFF_KERNEL_EXPLICIT: {
 #define LAUNCH_EXPLICIT(R_)                                                                                  \
     do {                                                                                                    \
         if (c->nt_explicit)                                                                                 \
             hipLaunchKernelGGL((k_sweep_explicit<R_, true>), dim3(pl.blocks), dim3(256), 0, c->stream, cf,  \
-                               xin, xout, c->nx, c->ny, pl.gx, pl.gy, flip, pl.omw);                        \
+                               xin, xout, c->nx, c->ny, c->rows, pl.cpi, mask, pl.gx, pl.gy, flip, pl.omw); \
         else                                                                                                \
             hipLaunchKernelGGL((k_sweep_explicit<R_, false>), dim3(pl.blocks), dim3(256), 0, c->stream, cf, \
-                               xin, xout, c->nx, c->ny, pl.gx, pl.gy, flip, pl.omw);                        \
+                               xin, xout, c->nx, c->ny, c->rows, pl.cpi, mask, pl.gx, pl.gy, flip, pl.omw); \
     } while (0)
         switch (pl.rows) {
         case 1: LAUNCH_EXPLICIT(1); break;
@@ -767,7 +831,7 @@ static inline void enqueue_sweep(deff_ctx *c, const SweepPlan &pl)
     default: {
 #define LAUNCH_MATFREE(V_, R_)                                                                               \
     hipLaunchKernelGGL((k_sweep_matfree<V_, R_>), dim3(pl.blocks), dim3(256), 0, c->stream, c->lut, c->code, \
-                       xin, xout, c->nx, c->ny, pl.gx, pl.gy, flip, pl.omw)
+                       xin, xout, c->nx, c->ny, c->rows, pl.cpi, mask, pl.gx, pl.gy, flip, pl.omw)
         if (c->nx & 1) {
             switch (pl.rows) {
             case 1: LAUNCH_MATFREE(1, 1); break;
@@ -796,9 +860,11 @@ static inline void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl)
     const double *xin = c->x[c->cur];
     double *xout = c->x[c->cur ^ 1];
     const int flip = c->serpentine ? c->cur : 0;
+    const uint8_t *mask = c->masked ? c->active : nullptr;
 #define LAUNCH_TB(T_, C_, G_)                                                                                  \
     hipLaunchKernelGGL((k_sweep_matfree_tb<T_, C_, G_>), dim3(pl.tblocks), dim3(256), 0, c->stream, c->lut_tb, \
-                       c->code, xin, xout, c->nx, c->ny, pl.LY, pl.ntx, pl.tgx, pl.tgy, flip, pl.omw)
+                       c->code, xin, xout, c->nx, c->ny, pl.tcpi, mask, pl.LY, pl.ntx, pl.tgx, pl.tgy, flip,  \
+                       c->tb_xmajor, pl.omw)
     TB_DISPATCH(pl.T, pl.CPL, pl.guard, LAUNCH_TB);
 #undef LAUNCH_TB
     c->cur ^= 1;
@@ -820,6 +886,7 @@ extern "C" int deff_sweeps(deff_ctx *c, int64_t nsweeps, double omega, float *ms
     TRY(use_device(c));
     SweepPlan pl;
     TRY(plan_sweeps(c, omega, &pl));
+    TRY(consolidate(c));
     c->last_launches = 0;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     enqueue_sweeps(c, pl, nsweeps);
@@ -830,42 +897,60 @@ extern "C" int deff_sweeps(deff_ctx *c, int64_t nsweeps, double omega, float *ms
     return DEFF_OK;
 }
 
-// Wall fluxes of the current field -> Deff (cuh:1252-1263), summed on the host
-// in row order like the reference.
-static int flux_now(deff_ctx *c, double *deff_raw, double *MFL, double *MFR)
+// Wall fluxes of the current field (cuh:1256-1257) for every stacked row, brought to the
+// pinned host buffer: mf_host[0..rows) left wall, mf_host[rows..2*rows) right wall.
+static int flux_rows(deff_ctx *c)
 {
     if (!c->have_walls)
         return fail(DEFF_ESTATE, "wall diffusivities unknown: pass D to deff_set_system() or assemble on the device");
-    hipLaunchKernelGGL(k_wall_flux, dim3((c->ny + 255) / 256), dim3(256), 0, c->stream, c->x[c->cur], c->Dl,
-                       c->Dr, c->nx, c->ny, c->dx, c->CL, c->CR, c->mf);
+    hipLaunchKernelGGL(k_wall_flux, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, c->x[c->cur], c->Dl,
+                       c->Dr, c->nx, c->rows, c->dx, c->CL, c->CR, c->mf);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(c->mf_host, c->mf, sizeof(double) * 2 * c->ny, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->mf_host, c->mf, sizeof(double) * 2 * c->rows, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    double Q1 = 0, Q2 = 0;
-    for (int j = 0; j < c->ny; ++j) {
-        Q1 += c->mf_host[j];
-        Q2 += c->mf_host[c->ny + j];
-    }
-    const double qAvg = (Q1 + Q2) / (2.0 * c->ny);
-    *deff_raw = qAvg / ((c->CR - c->CL));
-    if (MFL) memcpy(MFL, c->mf_host, sizeof(double) * c->ny);
-    if (MFR) memcpy(MFR, c->mf_host + c->ny, sizeof(double) * c->ny);
     return DEFF_OK;
 }
 
+// Deff of image k from its rows of mf_host, summed in row order like the reference (cuh:1258-1263).
+static double deff_of_image(const deff_ctx *c, int k)
+{
+    const double *L = c->mf_host + (size_t)k * c->ny, *R = c->mf_host + c->rows + (size_t)k * c->ny;
+    double Q1 = 0, Q2 = 0;
+    for (int j = 0; j < c->ny; ++j) {
+        Q1 += L[j];
+        Q2 += R[j];
+    }
+    const double qAvg = (Q1 + Q2) / (2.0 * c->ny);
+    return qAvg / ((c->CR - c->CL));
+}
+
+static void copy_fluxes(const deff_ctx *c, double *MFL, double *MFR)
+{
+    if (MFL) memcpy(MFL, c->mf_host, sizeof(double) * c->rows);
+    if (MFR) memcpy(MFR, c->mf_host + c->rows, sizeof(double) * c->rows);
+}
+
+// deff_raw: nimg values (one per stacked image); MFL/MFR: rows values each, may be NULL.
 extern "C" int deff_flux(deff_ctx *c, double *deff_raw, double *MFL, double *MFR)
 {
     if (!c || !deff_raw) return fail(DEFF_EINVAL, "NULL argument");
     if (!c->have_field) return fail(DEFF_ESTATE, "no field");
     TRY(use_device(c));
-    return flux_now(c, deff_raw, MFL, MFR);
+    TRY(consolidate(c));
+    TRY(flux_rows(c));
+    for (int k = 0; k < c->nimg; ++k) deff_raw[k] = deff_of_image(c, k);
+    copy_fluxes(c, MFL, MFR);
+    return DEFF_OK;
 }
 
-// JacobiGPU's loop, cuh:1232-1290, with the sweeps between two checks enqueued
-// without host round trips.  `iter` counts completed sweeps; the sweep with
-// 0-based index k is followed by a check iff k % check_every == 0 (cuh:1243).
-extern "C" int deff_solve(deff_ctx *c, double omega, double tol, int64_t max_iter, int64_t check_every,
-                          deff_result *out, double *MFL, double *MFR)
+// JacobiGPU's loop, cuh:1232-1290, with the sweeps between two checks enqueued without host
+// round trips.  `iter` counts completed sweeps; the sweep with 0-based index k is followed by a
+// check iff k % check_every == 0 (cuh:1243).  All images of a batch start together, so their
+// checks coincide; each image carries its own deffOld / change and drops out (is frozen in the
+// buffer it is in) as soon as ITS stopping rule fires -- exactly what a one-image-at-a-time run
+// of the reference's loop would do.
+extern "C" int deff_solve_batch(deff_ctx *c, double omega, double tol, int64_t max_iter, int64_t check_every,
+                                deff_result *out, double *MFL, double *MFR)
 {
     if (!c || !out) return fail(DEFF_EINVAL, "NULL argument");
     if (check_every < 1) return fail(DEFF_EINVAL, "check_every must be >= 1");
@@ -873,37 +958,75 @@ extern "C" int deff_solve(deff_ctx *c, double omega, double tol, int64_t max_ite
     SweepPlan pl;
     TRY(plan_sweeps(c, omega, &pl));
     if (!c->have_walls) return fail(DEFF_ESTATE, "wall diffusivities unknown (needed for Deff)");
+    TRY(consolidate(c));                                             // x is in/out: warm start from x[cur]
 
-    int64_t iter = 0, checks = 0;
+    const int B = c->nimg;
+    std::vector<double> deffNew(B, 1.0), deffOld(B, 5.0), change(B, 100.0), conv(B, 0.0);   // cuh:1171-1173
+    std::vector<int64_t> iters(B, 0), checks(B, 0);
+    int n_active = (max_iter > 0 && tol < 100.0) ? B : 0;           // cuh:1232 with change = 100
+    if (n_active == 0) c->active_h.assign(B, 0);
+    int64_t iter = 0;
     c->last_launches = 0;
-    double deffNew = 1, deffOld = 5, change = 100.0, conv = 0;      // cuh:1171-1173
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    while (iter < max_iter && tol < fabs(change)) {                  // cuh:1232
+    while (iter < max_iter && n_active > 0) {                        // cuh:1232
         const int64_t next_check = ((iter + check_every - 1) / check_every) * check_every;
         const bool do_check = next_check < max_iter;
         const int64_t batch = do_check ? next_check - iter + 1 : max_iter - iter;
         enqueue_sweeps(c, pl, batch);
         HIP_TRY(hipGetLastError());
         iter += batch;
+        for (int k = 0; k < B; ++k)
+            if (c->active_h[k]) { iters[k] = iter; c->buf_of[k] = (uint8_t)c->cur; }
         if (do_check) {
-            TRY(flux_now(c, &deffNew, MFL, MFR));
-            change = (deffOld - deffNew) / (deffOld);                // cuh:1265
-            deffOld = deffNew;
-            conv = change;                                           // cuh:1275
-            ++checks;
-            if (c->progress) c->progress(next_check, deffNew, change, c->progress_user);   // cuh:1267-1271
+            TRY(flux_rows(c));
+            bool froze = false;
+            for (int k = 0; k < B; ++k) {
+                if (!c->active_h[k]) continue;
+                deffNew[k] = deff_of_image(c, k);
+                change[k] = (deffOld[k] - deffNew[k]) / (deffOld[k]);           // cuh:1265
+                deffOld[k] = deffNew[k];
+                conv[k] = change[k];                                             // cuh:1275
+                ++checks[k];
+                if (B == 1 && c->progress) c->progress(next_check, deffNew[k], change[k], c->progress_user);
+                if (!(tol < fabs(change[k]))) { c->active_h[k] = 0; --n_active; froze = true; }
+            }
+            if (B == 1) copy_fluxes(c, MFL, MFR);
+            else {
+                // keep, per image, the fluxes of ITS last check
+                for (int k = 0; k < B; ++k)
+                    if (checks[k] && iters[k] == iter) {
+                        if (MFL) memcpy(MFL + (size_t)k * c->ny, c->mf_host + (size_t)k * c->ny, sizeof(double) * c->ny);
+                        if (MFR) memcpy(MFR + (size_t)k * c->ny, c->mf_host + c->rows + (size_t)k * c->ny,
+                                        sizeof(double) * c->ny);
+                    }
+            }
+            if (froze && n_active > 0) {
+                TRY(dev_alloc(&c->active, (size_t)B));
+                HIP_TRY(hipMemcpyAsync(c->active, c->active_h.data(), (size_t)B, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                c->masked = true;
+            }
         }
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    out->iters = iter;
-    out->checks = checks;
-    out->deff_raw = deffNew;                                         // cuh:1309: value at the last check
-    out->conv = conv;
-    out->loop_ms = ms;
+    for (int k = 0; k < B; ++k) {
+        out[k].iters = iters[k];
+        out[k].checks = checks[k];
+        out[k].deff_raw = deffNew[k];                                // cuh:1309: value at the last check
+        out[k].conv = conv[k];
+        out[k].loop_ms = ms;                                         // the batch shares one loop
+    }
     return DEFF_OK;
+}
+
+extern "C" int deff_solve(deff_ctx *c, double omega, double tol, int64_t max_iter, int64_t check_every,
+                          deff_result *out, double *MFL, double *MFR)
+{
+    if (c && c->nimg != 1) return fail(DEFF_EINVAL, "context holds %d images: use deff_solve_batch()", c->nimg);
+    return deff_solve_batch(c, omega, tol, max_iter, check_every, out, MFL, MFR);
 }
 
 extern "C" int deff_set_progress(deff_ctx *c, deff_progress_fn fn, void *user)
@@ -922,7 +1045,7 @@ extern "C" int deff_last_launches(const deff_ctx *c, int64_t *launches, int *swe
         int k = 0;
         *sweeps_per_pass = 1;
         if (resolve_kernel(c, &k) == DEFF_OK && k == DEFF_KERNEL_MATFREE_TB) {
-            int T = c->tb_T ? c->tb_T : 4;
+            int T = c->tb_T ? c->tb_T : (c->n >= ((size_t)1 << 22) ? 6 : 4);
             *sweeps_per_pass = T >= 8 ? 8 : T >= 6 ? 6 : T >= 4 ? 4 : 2;
         }
     }

@@ -2,6 +2,13 @@
 // coefficient assembly, layout import/export, initial guess, wall fluxes.
 // None of these is on the per-sweep path; they are written for exactness and
 // coalescing, not for the last percent.
+//
+// Batches: a context may hold `nimg` images of the same size stacked on top of
+// each other (image k = rows [k*ny, (k+1)*ny) of one tall array).  The zero-flux
+// top/bottom boundary of every image means no coefficient ever links two
+// images, so the stack is swept as a single domain; only the position class of
+// a row (first / last / interior row OF ITS IMAGE) has to be taken modulo ny.
+// Below `rows` = nimg*ny is the stacked height and `ny` the height of one image.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,41 +37,44 @@ __global__ void k_synth_mask(uint8_t *__restrict__ pix, int nx, int ny, uint64_t
 }
 
 // Pixel of mesh cell (i, j) under nearest-neighbour amplification, cuh:1992-1994.
-__device__ __forceinline__ uint8_t cell_pixel(const uint8_t *pix, int W, int ampX, int ampY,
+// (i is the stacked row: image i / ny, row i % ny of that image; H = ny / ampY.)
+__device__ __forceinline__ uint8_t cell_pixel(const uint8_t *pix, int W, int ampX, int ampY, int ny,
                                               int i, int j)
 {
-    return pix[(size_t)(i / ampY) * W + (j / ampX)];
+    const int img = i / ny, li = i - img * ny;
+    const int H = ny / ampY;
+    return pix[((size_t)img * H + (li / ampY)) * W + (j / ampX)];
 }
 
 // 2-phase D fill, cuh:1988-2000: pixel < 150 -> fluid.
 __global__ void k_fill_D_2phase(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
-                                int nx, int ny, double DCF, double DCS, double *__restrict__ D)
+                                int nx, int ny, int rows, double DCF, double DCS, double *__restrict__ D)
 {
-    const size_t n = (size_t)nx * ny;
+    const size_t n = (size_t)nx * rows;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
          p += (size_t)gridDim.x * blockDim.x) {
         int i = (int)(p / nx), j = (int)(p % nx);
-        D[p] = (cell_pixel(pix, W, ampX, ampY, i, j) < 150) ? DCF : DCS;
+        D[p] = (cell_pixel(pix, W, ampX, ampY, ny, i, j) < 150) ? DCF : DCS;
     }
 }
 
 // Diffusivity of the first and last cell of every row, for the wall fluxes
 // (cuh:1256-1257 read D[j*nx] and D[(j+1)*nx-1]).
 __global__ void k_wall_D_2phase(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
-                                int nx, int ny, double DCF, double DCS,
+                                int nx, int ny, int rows, double DCF, double DCS,
                                 double *__restrict__ Dl, double *__restrict__ Dr)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ny) return;
-    Dl[i] = (cell_pixel(pix, W, ampX, ampY, i, 0) < 150) ? DCF : DCS;
-    Dr[i] = (cell_pixel(pix, W, ampX, ampY, i, nx - 1) < 150) ? DCF : DCS;
+    if (i >= rows) return;
+    Dl[i] = (cell_pixel(pix, W, ampX, ampY, ny, i, 0) < 150) ? DCF : DCS;
+    Dr[i] = (cell_pixel(pix, W, ampX, ampY, ny, i, nx - 1) < 150) ? DCF : DCS;
 }
 
-__global__ void k_wall_D_from_D(const double *__restrict__ D, int nx, int ny,
+__global__ void k_wall_D_from_D(const double *__restrict__ D, int nx, int rows,
                                 double *__restrict__ Dl, double *__restrict__ Dr)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ny) return;
+    if (i >= rows) return;
     Dl[i] = D[(size_t)i * nx];
     Dr[i] = D[(size_t)(i + 1) * nx - 1];
 }
@@ -75,19 +85,20 @@ __global__ void k_wall_D_from_D(const double *__restrict__ D, int nx, int ny,
 // neighbour phases.  Neighbours outside the mesh read the clamped cell; their bits are
 // never used because the lookup tables are selected by position class.
 __global__ void k_phase_codes(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
-                              int nx, int ny, uint8_t *__restrict__ code)
+                              int nx, int ny, int rows, uint8_t *__restrict__ code)
 {
-    const size_t n = (size_t)nx * ny;
+    const size_t n = (size_t)nx * rows;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
          p += (size_t)gridDim.x * blockDim.x) {
         int i = (int)(p / nx), j = (int)(p % nx);
+        const int li = i % ny;                       // row inside its image
         int jw = j > 0 ? j - 1 : j, je = j < nx - 1 ? j + 1 : j;
-        int is = i < ny - 1 ? i + 1 : i, in = i > 0 ? i - 1 : i;
-        unsigned c = (cell_pixel(pix, W, ampX, ampY, i, j) >= 150) ? 1u : 0u;
-        c |= (cell_pixel(pix, W, ampX, ampY, i, jw) >= 150) ? 2u : 0u;
-        c |= (cell_pixel(pix, W, ampX, ampY, i, je) >= 150) ? 4u : 0u;
-        c |= (cell_pixel(pix, W, ampX, ampY, is, j) >= 150) ? 8u : 0u;
-        c |= (cell_pixel(pix, W, ampX, ampY, in, j) >= 150) ? 16u : 0u;
+        int is = li < ny - 1 ? i + 1 : i, in = li > 0 ? i - 1 : i;
+        unsigned c = (cell_pixel(pix, W, ampX, ampY, ny, i, j) >= 150) ? 1u : 0u;
+        c |= (cell_pixel(pix, W, ampX, ampY, ny, i, jw) >= 150) ? 2u : 0u;
+        c |= (cell_pixel(pix, W, ampX, ampY, ny, i, je) >= 150) ? 4u : 0u;
+        c |= (cell_pixel(pix, W, ampX, ampY, ny, is, j) >= 150) ? 8u : 0u;
+        c |= (cell_pixel(pix, W, ampX, ampY, ny, in, j) >= 150) ? 16u : 0u;
         code[p] = (uint8_t)(c << 3);
     }
 }
@@ -102,13 +113,13 @@ struct CoefSoA {
 // with Grid != nullptr, DiscretizeMatrix2D_ImpSolid cuh:715-812: Grid 1 or 2
 // gets the identity row, cuh:750-752).
 __global__ void k_assemble_from_D(const double *__restrict__ D, const unsigned int *__restrict__ Grid,
-                                  int nx, int ny, double dx, double dy, double CL, double CR,
+                                  int nx, int ny, int rows, double dx, double dy, double CL, double CR,
                                   CoefSoA c)
 {
-    const size_t n = (size_t)nx * ny;
+    const size_t n = (size_t)nx * rows;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
          p += (size_t)gridDim.x * blockDim.x) {
-        int i = (int)(p / nx), j = (int)(p % nx);
+        int i = (int)(p / nx) % ny, j = (int)(p % nx);   // i: row inside its image
         FvmRow r;
         if (Grid != nullptr && (Grid[p] == 1 || Grid[p] == 2)) {
             r.a0 = 1; r.aW = 0; r.aE = 0; r.aS = 0; r.aN = 0; r.b = 0;
@@ -159,9 +170,9 @@ __global__ void k_make_c0(const double *__restrict__ a0, double w, double *__res
 // ---------------------------------------------------------------- field ---
 
 // Linear ramp, cuh:1955-1959: (double)j/nx*(CR-CL)+CL.
-__global__ void k_init_linear(double *__restrict__ x, int nx, int ny, double CL, double CR)
+__global__ void k_init_linear(double *__restrict__ x, int nx, int rows, double CL, double CR)
 {
-    const size_t n = (size_t)nx * ny;
+    const size_t n = (size_t)nx * rows;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
          p += (size_t)gridDim.x * blockDim.x) {
         int j = (int)(p % nx);
@@ -173,13 +184,13 @@ __global__ void k_init_linear(double *__restrict__ x, int nx, int ny, double CL,
 // (cuh:1258-1259) so Deff has the reference's summation order; the transfer is
 // 16*ny bytes per check instead of the reference's whole field (cuh:1245).
 __global__ void k_wall_flux(const double *__restrict__ x, const double *__restrict__ Dl,
-                            const double *__restrict__ Dr, int nx, int ny, double dx,
+                            const double *__restrict__ Dr, int nx, int rows, double dx,
                             double CL, double CR, double *__restrict__ mf)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ny) return;
+    if (i >= rows) return;
     mf[i] = Dl[i] * (x[(size_t)i * nx] - CL) / (dx / 2.0);
-    mf[ny + i] = Dr[i] * (CR - x[(size_t)(i + 1) * nx - 1]) / (dx / 2.0);
+    mf[rows + i] = Dr[i] * (CR - x[(size_t)(i + 1) * nx - 1]) / (dx / 2.0);
 }
 
 }  // namespace deff

@@ -79,10 +79,12 @@ __device__ __forceinline__ double ldc(const double *p)
 template <bool NT>
 __global__ __launch_bounds__(256) void k_sweep_scalar(CoefConst c, const double *__restrict__ x,
                                                       double *__restrict__ xnew, int nx, size_t n,
+                                                      size_t n_img, const uint8_t *__restrict__ active,
                                                       double omw)
 {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
+    if (active && !active[p / n_img]) return;       // frozen image of a batch
     const double xw = (p >= 1) ? x[p - 1] : 0.0;
     const double xe = (p + 1 < n) ? x[p + 1] : 0.0;
     const double xs = (p + nx < n) ? x[p + nx] : 0.0;
@@ -118,17 +120,25 @@ __device__ __forceinline__ double2 ldc2(const double *p)
 // first use, so (R+2) x-rows and 6R coefficient vectors are in flight per lane.
 // (A version that marched down many rows with a rolling 3-row window was
 // latency-bound: one dependent global round trip per row.)
+// Batches (see kernels_setup.hpp): `ny` rows per image, `rows` stacked rows, `cpi` row
+// tiles per image (tiles never straddle two images); `active` (may be null) marks the
+// images still being iterated.
 template <int R, bool NT>
 __global__ __launch_bounds__(256) void k_sweep_explicit(CoefConst c, const double *__restrict__ x,
                                                         double *__restrict__ xnew, int nx, int ny,
-                                                        int gx, int gy, int flip, double omw)
+                                                        int rows, int cpi,
+                                                        const uint8_t *__restrict__ active, int gx,
+                                                        int gy, int flip, double omw)
 {
     int bx, by;
     if (!xcd_tile(gx, gy, flip, bx, by)) return;
     const int col = (bx * 256 + (int)threadIdx.x) * 2;
     if (col >= nx) return;
-    const int r0 = by * R;
-    const size_t n = (size_t)nx * ny;
+    const int img = by / cpi;
+    if (active && !active[img]) return;
+    const int r0 = img * ny + (by - img * cpi) * R;
+    const int rlim = (img + 1) * ny;
+    const size_t n = (size_t)nx * rows;
     const size_t p0 = (size_t)r0 * nx + col;
     const double2 zero = make_double2(0.0, 0.0);
 
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(256) void k_sweep_explicit(CoefConst c, const doubl
     }
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        if (r0 + k >= ny) break;
+        if (r0 + k >= rlim) break;
         const size_t p = p0 + (size_t)k * nx;
         const double2 c0 = ldc2<NT>(c.c0 + p), aW = ldc2<NT>(c.aW + p), aE = ldc2<NT>(c.aE + p);
         const double2 aS = ldc2<NT>(c.aS + p), aN = ldc2<NT>(c.aN + p), b = ldc2<NT>(c.b + p);
@@ -197,13 +207,15 @@ __global__ __launch_bounds__(256) void k_sweep_matfree(const double *__restrict_
                                                        const uint8_t *__restrict__ code,
                                                        const double *__restrict__ x,
                                                        double *__restrict__ xnew, int nx, int ny,
-                                                       int gx, int gy, int flip, double omw)
+                                                       int rows, int cpi,
+                                                       const uint8_t *__restrict__ active, int gx,
+                                                       int gy, int flip, double omw)
 {
     __shared__ double lut[LUT_DOUBLES];
     for (int k = threadIdx.x; k < LUT_DOUBLES; k += 256) lut[k] = lut_g[k];
     __syncthreads();
 
-    const size_t n = (size_t)nx * ny;
+    const size_t n = (size_t)nx * rows;
     const unsigned total = (unsigned)gx * (unsigned)gy;
     const unsigned per = (total + 7u) / 8u;              // tiles per XCD
     const unsigned xcd = blockIdx.x & 7u;
@@ -215,7 +227,11 @@ __global__ __launch_bounds__(256) void k_sweep_matfree(const double *__restrict_
         tile_coords(t, gy, bx, by);
         const int col = (bx * 256 + (int)threadIdx.x) * VEC;
         if (col >= nx) continue;
-        const int r0 = by * R;
+        const int img = by / cpi;
+        if (active && !active[img]) continue;
+        const int row_lo = img * ny;                      // first stacked row of this image
+        const int r0 = row_lo + (by - img * cpi) * R;
+        const int rlim = row_lo + ny;
         const size_t p0 = (size_t)r0 * nx + col;
 
         if constexpr (VEC == 2) {
@@ -241,9 +257,9 @@ __global__ __launch_bounds__(256) void k_sweep_matfree(const double *__restrict_
 #pragma unroll
             for (int q = 0; q < R; ++q) {
                 const int r = r0 + q;
-                if (r >= ny) break;
+                if (r >= rlim) break;
                 const size_t p = p0 + (size_t)q * nx;
-                const int ycls = (r == 0) ? 1 : (r == ny - 1 ? 2 : 0);
+                const int ycls = (r == row_lo) ? 1 : (r == rlim - 1 ? 2 : 0);
                 const int i0 = (ycls * 3 + xcls0) * LUT_CODES + (int)((cc[q] >> 3) & 31u);
                 const int i1 = (ycls * 3 + xcls1) * LUT_CODES + (int)((cc[q] >> 11) & 31u);
                 const double2 xm = xr[q], xc = xr[q + 1], xp = xr[q + 2];
@@ -272,9 +288,9 @@ __global__ __launch_bounds__(256) void k_sweep_matfree(const double *__restrict_
 #pragma unroll
             for (int q = 0; q < R; ++q) {
                 const int r = r0 + q;
-                if (r >= ny) break;
+                if (r >= rlim) break;
                 const size_t p = p0 + (size_t)q * nx;
-                const int ycls = (r == 0) ? 1 : (r == ny - 1 ? 2 : 0);
+                const int ycls = (r == row_lo) ? 1 : (r == rlim - 1 ? 2 : 0);
                 const int i0 = (ycls * 3 + xcls) * LUT_CODES + (int)((cc[q] >> 3) & 31u);
                 xnew[p] = jacobi_cell_lut(lut, i0, xr[q + 1], xw[q], xe[q], xr[q + 2], xr[q], omw);
             }

@@ -41,6 +41,7 @@ namespace deff {
 constexpr int TB_CLASSES = 16;
 constexpr int TB_PLANE_STRIDE = TB_CLASSES * LUT_CODES + 8;    // 520 doubles
 constexpr int TB_LUT_DOUBLES = LUT_PLANES * TB_PLANE_STRIDE;   // 3120 doubles = 24.4 KiB
+constexpr int TB_COLS = 128;                                   // columns per wave strip (2 per lane)
 
 // lane i <- lane i-1 (lane 0 <- 0.0)
 __device__ __forceinline__ double from_lane_below(double v)
@@ -98,137 +99,126 @@ __device__ __forceinline__ int tb_ycls(int r, int ny)
     return (r < 0 || r >= ny) ? 3 : (r == 0 ? 1 : (r == ny - 1 ? 2 : 0));
 }
 
-// One strip x chunk: the whole row pipeline of a wave.  CPL = cells per lane: the
-// strip is 64*CPL columns wide and produces 64*CPL - 2T valid columns.  Written for
-// any even CPL; only CPL = 2 is instantiated (4 was measured slower, see deff_amd.hip).
-template <int T, int CPL, bool GUARD, bool WALL>
+// One strip x chunk: the whole row pipeline of a wave (2 cells per lane, 128 columns).
+// The chunk is rows [ry0, ry0+LY) of the image occupying stacked rows [row_lo, row_lo+ny);
+// rows outside that image are "outside the mesh" even if another image of the batch lives there.
+// (Variants measured and dropped: 4 cells per lane -- 244 VGPRs, 2 waves/SIMD, 20 % slower;
+// a skewed pipeline whose T updates per step are independent -- 198 VGPRs, no faster.  The
+// code is deliberately written with double2 values and named slots: an array-of-scalars
+// formulation of the same dataflow made hipcc hoist the lookups to 204 VGPRs.)
+template <int T, bool GUARD, bool WALL>
 __device__ __forceinline__ void tb_strip(const double *lut, const uint8_t *__restrict__ code,
                                          const double *__restrict__ x, double *__restrict__ xnew, int nx,
-                                         int ny, int tx, int ry0, int LY, int lane, double omw)
+                                         int ny, int row_lo, int tx, int ry0, int LY, int lane, double omw)
 {
-    constexpr int NP = CPL / 2;                    // 16-B pairs per lane
-    constexpr int WOUT = 64 * CPL - 2 * T;
+    constexpr int WOUT = TB_COLS - 2 * T;
     const int cx0 = tx * WOUT;                     // first output column of the strip
-    const int col = cx0 - T + CPL * lane;          // this lane's first column (even)
-    const int ry1 = min(ry0 + LY, ny);
+    const int col = cx0 - T + 2 * lane;            // this lane's first column (even)
+    const bool in_x = (col >= 0) && (col < nx);    // nx even => col+1 < nx too
+    const int row_hi = row_lo + ny;
+    const int ry1 = min(ry0 + LY, row_hi);
     const int r_begin = ry0 - T, r_end = ry1 + T;  // input rows [r_begin, r_end)
-    bool in_x[NP], st_x[NP];
-    unsigned xoff[CPL];                            // byte offset of each cell's x position class group
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        const int c = col + 2 * q;
-        in_x[q] = (c >= 0) && (c < nx);            // nx even => c+1 < nx too
-        st_x[q] = in_x[q] && (c >= cx0) && (c < cx0 + WOUT);
-        xoff[2 * q] = (unsigned)(!in_x[q] ? 3 : (c == 0 ? 1 : 0)) * (LUT_CODES * 8);
-        xoff[2 * q + 1] = (unsigned)(!in_x[q] ? 3 : (c + 1 == nx - 1 ? 2 : 0)) * (LUT_CODES * 8);
-    }
+    const bool st_x = in_x && (col >= cx0) && (col < cx0 + WOUT);
+    // byte offsets of the two cells' x position class groups (3 = outside the mesh)
+    const unsigned xoff0 = (unsigned)(!in_x ? 3 : (col == 0 ? 1 : 0)) * (LUT_CODES * 8);
+    const unsigned xoff1 = (unsigned)(!in_x ? 3 : (col + 1 == nx - 1 ? 2 : 0)) * (LUT_CODES * 8);
     const double2 zero = make_double2(0.0, 0.0);
 
-    double w[T][3][CPL];                           // w[t][slot]: 3 newest rows of sweep t
-    unsigned cw[T + 1][NP];                        // cw[t]: codes of row rr-t (2 per 16-bit pair)
+    double2 w[T][3];                               // w[t]: 3 newest rows of sweep t
+    unsigned cw[T + 1];                            // cw[t]: codes of row rr-t
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int t = 0; t < T; ++t) { w[t][0] = zero; w[t][1] = zero; w[t][2] = zero; }
 #pragma unroll
-        for (int sl = 0; sl < 3; ++sl)
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) w[t][sl][q] = 0.0;
-#pragma unroll
-    for (int t = 0; t <= T; ++t)
-#pragma unroll
-        for (int q = 0; q < NP; ++q) cw[t][q] = 0u;
+    for (int t = 0; t <= T; ++t) cw[t] = 0u;
 
-    double2 nx_x[3][NP];
-    unsigned nx_c[3][NP];
-    auto fetch = [&](int rr, double2 *vx, unsigned *vc) {
-        const bool row_ok = rr >= 0 && rr < ny && rr < r_end;
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const bool ok = row_ok && in_x[q];
-            const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col + 2 * q : 0);
-            vx[q] = ok ? ld2(x + p) : zero;
-            vc[q] = ok ? (unsigned)*reinterpret_cast<const uint16_t *>(code + p) : 0u;
-        }
-    };
     // prefetch the first group of three rows
+    double2 nx_x[3];
+    unsigned nx_c[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) fetch(r_begin + k, nx_x[k], nx_c[k]);
+    for (int k = 0; k < 3; ++k) {
+        const int rr = r_begin + k;
+        const bool ok = in_x && rr >= row_lo && rr < row_hi && rr < r_end;
+        const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col : 0);
+        nx_x[k] = ok ? ld2(x + p) : zero;
+        nx_c[k] = ok ? (unsigned)*reinterpret_cast<const uint16_t *>(code + p) : 0u;
+    }
 
-    // (A skewed variant -- sweep t working from the previous step's rows so that the T updates
-    // of a step are independent -- was measured: hipcc hoists every lookup, 198 VGPRs at T = 4,
-    // 2 waves per SIMD, no faster; constrained to 128 VGPRs it spills.  Not kept.)
     for (int r = r_begin; r < r_end; r += 3) {
-        double2 cur_x[3][NP];
-        unsigned cur_c[3][NP];
+        double2 cur_x[3];
+        unsigned cur_c[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int q = 0; q < NP; ++q) { cur_x[k][q] = nx_x[k][q]; cur_c[k][q] = nx_c[k][q]; }
+        for (int k = 0; k < 3; ++k) { cur_x[k] = nx_x[k]; cur_c[k] = nx_c[k]; }
         // issue the next group's loads before working on this one
 #pragma unroll
-        for (int k = 0; k < 3; ++k) fetch(r + 3 + k, nx_x[k], nx_c[k]);
+        for (int k = 0; k < 3; ++k) {
+            const int rr = r + 3 + k;
+            const bool ok = in_x && rr >= row_lo && rr < row_hi && rr < r_end;
+            const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col : 0);
+            nx_x[k] = ok ? ld2(x + p) : zero;
+            nx_c[k] = ok ? (unsigned)*reinterpret_cast<const uint16_t *>(code + p) : 0u;
+        }
 #pragma unroll
         for (int ph = 0; ph < 3; ++ph) {
             const int rr = r + ph;                 // input row of this step
             // after this step's level-(t-1) write: newest = slot ph, previous = (ph+2)%3, oldest = (ph+1)%3
             const int sN = (ph + 1) % 3, sC = (ph + 2) % 3, sS = ph;
 #pragma unroll
-            for (int t = T; t >= 1; --t)
-#pragma unroll
-                for (int q = 0; q < NP; ++q) cw[t][q] = cw[t - 1][q];
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                cw[0][q] = cur_c[ph][q];
-                w[0][sS][2 * q] = cur_x[ph][q].x;
-                w[0][sS][2 * q + 1] = cur_x[ph][q].y;
-            }
+            for (int t = T; t >= 1; --t) cw[t] = cw[t - 1];
+            cw[0] = cur_c[ph];
+            w[0][sS] = cur_x[ph];
 #pragma unroll
             for (int t = 1; t <= T; ++t) {
                 const int rt = rr - t;             // row produced by sweep t in this step
-                const double *vN = w[t - 1][sN], *vC = w[t - 1][sC], *vS = w[t - 1][sS];
-                const double xw_first = from_lane_below(vC[CPL - 1]);
-                const double xe_last = from_lane_above(vC[0]);
+                const double2 vN = w[t - 1][sN], vC = w[t - 1][sC], vS = w[t - 1][sS];
+                const double xw0 = from_lane_below(vC.y);
+                const double xe1 = from_lane_above(vC.x);
                 // byte offset = class group (multiple of 256) | pre-scaled code (< 256)
-                const unsigned ybase = (unsigned)tb_ycls(rt, ny) * (4 * LUT_CODES * 8);
-                double o[CPL];
-#pragma unroll
-                for (int q = 0; q < CPL; ++q) {
-                    const unsigned cbits = (q & 1) ? (cw[t][q >> 1] >> 8) : cw[t][q >> 1];
-                    const unsigned off = (cbits & 0xF8u) | (ybase + xoff[q]);
-                    const double xw = (q == 0) ? xw_first : vC[q - 1];
-                    const double xe = (q == CPL - 1) ? xe_last : vC[q + 1];
-                    o[q] = tb_cell<GUARD, WALL>(lut, off, vC[q], xw, xe, vS[q], vN[q], omw);
-                }
+                const unsigned ybase = (unsigned)tb_ycls(rt - row_lo, ny) * (4 * LUT_CODES * 8);
+                const unsigned o0 = (cw[t] & 0xF8u) | (ybase + xoff0);
+                const unsigned o1 = ((cw[t] >> 8) & 0xF8u) | (ybase + xoff1);
+                double2 o;
+                o.x = tb_cell<GUARD, WALL>(lut, o0, vC.x, xw0, vC.y, vS.x, vN.x, omw);
+                o.y = tb_cell<GUARD, WALL>(lut, o1, vC.y, vC.x, xe1, vS.y, vN.y, omw);
                 if (t < T) {
-#pragma unroll
-                    for (int q = 0; q < CPL; ++q) w[t][sS][q] = o[q];
-                } else if (rt >= ry0 && rt < ry1) {
-#pragma unroll
-                    for (int q = 0; q < NP; ++q)
-                        if (st_x[q]) st2(xnew + (size_t)rt * nx + col + 2 * q, make_double2(o[2 * q], o[2 * q + 1]));
+                    w[t][sS] = o;
+                } else if (st_x && rt >= ry0 && rt < ry1) {
+                    st2(xnew + (size_t)rt * nx + col, o);
                 }
+                // keep the scheduler from pulling the next sweeps' table lookups up here: left
+                // alone it hoists them all (180-250 VGPRs, 1-2 waves per SIMD); with the fence a
+                // step keeps ~120 VGPRs and 4 waves per SIMD hide the LDS latency instead
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
 }
 
-// grid: persistent workgroups of 4 waves; wave w of block-tile (btx, bty) owns
-// strip tx = btx*4 + w and rows [bty*LY, bty*LY + LY).  nx must be even, T even.
+// grid: persistent workgroups of 4 waves.  Wave tiles (strip tx, chunk ty) are numbered
+// strip-major (wt = tx*gy + ty) and dealt 4 per workgroup, so the 4 waves of a workgroup
+// normally hold 4 vertically adjacent chunks of one strip (shared halo rows stay in L1/L2)
+// and no wave idles because the strip count is not a multiple of 4.  `gx` = number of
+// workgroup tiles = ceil(ntx*gy / 4); gy = nimg * cpi chunks.  nx must be even, T even.
 template <int T, int CPL, bool GUARD>
 __global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restrict__ lut_g,
                                                           const uint8_t *__restrict__ code,
                                                           const double *__restrict__ x,
                                                           double *__restrict__ xnew, int nx, int ny,
-                                                          int LY, int ntx, int gx, int gy, int flip,
-                                                          double omw)
+                                                          int cpi, const uint8_t *__restrict__ active,
+                                                          int LY, int ntx, int nbt, int gy, int flip,
+                                                          int xmajor, double omw)
 {
-    static_assert(T >= 1 && T <= 8 && (CPL == 2 || CPL == 4), "unsupported T / CPL");
+    static_assert(T >= 1 && T <= 8 && CPL == 2, "unsupported T / cells per lane");
     __shared__ double lut[TB_LUT_DOUBLES];
     for (int k = threadIdx.x; k < TB_LUT_DOUBLES; k += 256) lut[k] = lut_g[k];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const unsigned total = (unsigned)gx * (unsigned)gy;
+    // readfirstlane makes the wave index (and everything derived from it: strip, chunk, row
+    // classes, loop bounds) provably wave-uniform, i.e. SGPR/SALU work; left as a VGPR it
+    // costs ~80 VGPRs of per-lane copies of scalars
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned total = (unsigned)nbt;              // workgroup tiles
+    const unsigned wtiles = (unsigned)ntx * (unsigned)gy;
     const unsigned per = (total + 7u) / 8u;
     const unsigned xcd = blockIdx.x & 7u;
     const unsigned nper = gridDim.x >> 3;
@@ -236,14 +226,20 @@ __global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restri
     for (unsigned kk = blockIdx.x >> 3; kk < per; kk += nper) {
         const unsigned bt = xcd * per + (flip ? per - 1u - kk : kk);
         if (bt >= total) continue;
-        const int btx = (int)(bt / (unsigned)gy), bty = (int)(bt % (unsigned)gy);
-        const int tx = btx * 4 + wave;
-        if (tx >= ntx) continue;                       // wave-uniform
+        const unsigned wt = bt * 4u + (unsigned)wave;
+        if (wt >= wtiles) continue;                    // wave-uniform
+        // strip-major: 4 waves = 4 stacked chunks of one strip; x-major: 4 neighbouring strips
+        const int tx = xmajor ? (int)(wt % (unsigned)ntx) : (int)(wt / (unsigned)gy);
+        const int bty = xmajor ? (int)(wt / (unsigned)ntx) : (int)(wt % (unsigned)gy);
+        const int img = bty / cpi;                     // cpi chunks per image, gy = nimg * cpi
+        if (active && !active[img]) continue;          // frozen image of a batch
+        const int row_lo = img * ny;
+        const int ry0 = row_lo + (bty - img * cpi) * LY;
 
         if (tx == 0 || tx == ntx - 1)
-            tb_strip<T, CPL, GUARD, true>(lut, code, x, xnew, nx, ny, tx, bty * LY, LY, lane, omw);
+            tb_strip<T, GUARD, true>(lut, code, x, xnew, nx, ny, row_lo, tx, ry0, LY, lane, omw);
         else
-            tb_strip<T, CPL, GUARD, false>(lut, code, x, xnew, nx, ny, tx, bty * LY, LY, lane, omw);
+            tb_strip<T, GUARD, false>(lut, code, x, xnew, nx, ny, row_lo, tx, ry0, LY, lane, omw);
     }
 }
 

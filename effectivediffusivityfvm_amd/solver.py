@@ -23,11 +23,15 @@ class SolveResult:
 
 
 class Solver:
-    def __init__(self, nx, ny, device=0, kernel="auto"):
+    """One context: `nimg` images of an nx x ny mesh (nimg > 1 = dataset-generation batch,
+    arrays are then stacked image after image: shape (nimg*ny, nx))."""
+
+    def __init__(self, nx, ny, device=0, kernel="auto", nimg=1):
         self._L = _capi.load()
         self._ctx = C.c_void_p()
-        self.nx, self.ny = int(nx), int(ny)
-        check(self._L.deff_create(int(device), self.nx, self.ny, C.byref(self._ctx)))
+        self.nx, self.ny, self.nimg = int(nx), int(ny), int(nimg)
+        self.rows = self.ny * self.nimg
+        check(self._L.deff_create_batch(int(device), self.nx, self.ny, self.nimg, C.byref(self._ctx)))
         if kernel != "auto":
             self.set_kernel(kernel)
 
@@ -64,14 +68,19 @@ class Solver:
     # -- image / assembly -------------------------------------------------
     def set_image(self, pix, ampX=1, ampY=1):
         pix = np.ascontiguousarray(pix, dtype=np.uint8)
-        H, W = pix.shape
-        check(self._L.deff_set_image(self._ctx, pix, W, H, ampX, ampY))
+        if pix.ndim == 3:                                   # (nimg, H, W)
+            assert pix.shape[0] == self.nimg
+            H, W = pix.shape[1:]
+        else:                                               # (nimg*H, W)
+            assert pix.shape[0] % self.nimg == 0
+            H, W = pix.shape[0] // self.nimg, pix.shape[1]
+        check(self._L.deff_set_image(self._ctx, pix.reshape(-1, W), W, H, ampX, ampY))
 
     def synth_image(self, seed=12345, img=0):
         check(self._L.deff_synth_image(self._ctx, seed, img))
 
     def get_image(self):
-        out = np.empty((self.ny, self.nx), dtype=np.uint8)   # only valid for amp 1
+        out = np.empty((self.rows, self.nx), dtype=np.uint8)   # only valid for amp 1
         check(self._L.deff_get_image(self._ctx, out))
         return out
 
@@ -96,7 +105,7 @@ class Solver:
         check(self._L.deff_set_system(self._ctx, A, b, d, CL, CR))
 
     def get_system(self):
-        n = self.nx * self.ny
+        n = self.nx * self.rows
         A = np.empty((n, 5), dtype=np.float64)
         b = np.empty(n, dtype=np.float64)
         check(self._L.deff_get_system(self._ctx, A, b))
@@ -108,26 +117,32 @@ class Solver:
 
     def set_field(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
-        assert x.size == self.nx * self.ny
+        assert x.size == self.nx * self.rows
         check(self._L.deff_set_field(self._ctx, x))
 
     def get_field(self):
-        x = np.empty((self.ny, self.nx), dtype=np.float64)
+        x = np.empty((self.rows, self.nx), dtype=np.float64)
         check(self._L.deff_get_field(self._ctx, x))
         return x
 
     # -- solve ------------------------------------------------------------
     def solve(self, tol, max_iter, omega=OMEGA_REFERENCE, check_every=10000):
-        res = Result()
-        MFL = np.zeros(self.ny)
-        MFR = np.zeros(self.ny)
-        check(self._L.deff_solve(self._ctx, omega, tol, int(max_iter), int(check_every), C.byref(res),
-                                 MFL.ctypes.data_as(C.c_void_p), MFR.ctypes.data_as(C.c_void_p)))
-        out = SolveResult()
-        out.iters, out.checks = res.iters, res.checks
-        out.deff_raw, out.conv, out.loop_ms = res.deff_raw, res.conv, res.loop_ms
-        out.MFL, out.MFR = MFL, MFR
-        return out
+        """One image: a SolveResult.  Batch: a list with one SolveResult per image (MFL/MFR
+        are that image's rows)."""
+        res = (Result * self.nimg)()
+        MFL = np.zeros(self.rows)
+        MFR = np.zeros(self.rows)
+        check(self._L.deff_solve_batch(self._ctx, omega, tol, int(max_iter), int(check_every), res,
+                                       MFL.ctypes.data_as(C.c_void_p), MFR.ctypes.data_as(C.c_void_p)))
+        outs = []
+        for k in range(self.nimg):
+            out = SolveResult()
+            out.iters, out.checks = res[k].iters, res[k].checks
+            out.deff_raw, out.conv, out.loop_ms = res[k].deff_raw, res[k].conv, res[k].loop_ms
+            out.MFL = MFL[k * self.ny:(k + 1) * self.ny]
+            out.MFR = MFR[k * self.ny:(k + 1) * self.ny]
+            outs.append(out)
+        return outs[0] if self.nimg == 1 else outs
 
     def sweeps(self, n, omega=OMEGA_REFERENCE):
         ms = C.c_float()
@@ -135,12 +150,11 @@ class Solver:
         return ms.value
 
     def flux(self):
-        d = C.c_double()
-        MFL = np.zeros(self.ny)
-        MFR = np.zeros(self.ny)
-        check(self._L.deff_flux(self._ctx, C.byref(d), MFL.ctypes.data_as(C.c_void_p),
-                                MFR.ctypes.data_as(C.c_void_p)))
-        return d.value, MFL, MFR
+        d = (C.c_double * self.nimg)()
+        MFL = np.zeros(self.rows)
+        MFR = np.zeros(self.rows)
+        check(self._L.deff_flux(self._ctx, d, MFL.ctypes.data_as(C.c_void_p), MFR.ctypes.data_as(C.c_void_p)))
+        return (d[0] if self.nimg == 1 else np.array(d[:])), MFL, MFR
 
     def set_progress(self, fn):
         """fn(iter, deff_raw, change) after every convergence check, or None."""

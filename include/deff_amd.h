@@ -64,6 +64,13 @@ int deff_device_count(int *count);
 
 /* ---- lifecycle: replaces initializeGPU cuh:904-981 / unInitializeGPU cuh:983-1021 */
 int deff_create(int device, int nx, int ny, deff_ctx **out);
+/* dataset-generation mode (BatchSim cuh:1843-2054): `nimg` images of the same nx x ny mesh are
+ * held and swept together as one stacked domain (image k = rows [k*ny, (k+1)*ny)); every
+ * array argument of the calls below then covers the whole stack, image after image.  The
+ * zero-flux top/bottom boundaries keep the images uncoupled, so each image's numbers are
+ * those of a one-at-a-time run. */
+int deff_create_batch(int device, int nx, int ny, int nimg, deff_ctx **out);
+int deff_batch_size(const deff_ctx *ctx, int *nimg);
 int deff_destroy(deff_ctx *ctx);
 int deff_mesh(const deff_ctx *ctx, int *nx, int *ny, double *dx, double *dy);   /* meshInfo cuh:54-61 */
 int deff_set_kernel(deff_ctx *ctx, int kernel);
@@ -104,6 +111,10 @@ int deff_get_field(deff_ctx *ctx, double *x);                       /* final D2H
  * fluxes of the last check (cuh:1256-1257). */
 int deff_solve(deff_ctx *ctx, double omega, double tol, int64_t max_iter, int64_t check_every,
                deff_result *out, double *MFL, double *MFR);
+/* same loop for a batch context: out[nimg]; each image stops by its own rule (its sweeps
+ * end, its field is frozen) while the others continue; MFL/MFR hold nimg*ny values */
+int deff_solve_batch(deff_ctx *ctx, double omega, double tol, int64_t max_iter, int64_t check_every,
+                     deff_result *out, double *MFL, double *MFR);
 /* optional observer called on the host after every convergence check with
  * (iter of the checked sweep, Deff, signed change): what the reference prints under
  * Verbose (cuh:1267-1271).  NULL removes it. */
@@ -112,7 +123,7 @@ int deff_set_progress(deff_ctx *ctx, deff_progress_fn fn, void *user);
 /* building blocks, also used by bench.py: n sweeps without a check (ms = hipEvent
  * time on the context's stream), and one flux / Deff evaluation (cuh:1252-1263) */
 int deff_sweeps(deff_ctx *ctx, int64_t n, double omega, float *ms);
-int deff_flux(deff_ctx *ctx, double *deff_raw, double *MFL, double *MFR);
+int deff_flux(deff_ctx *ctx, double *deff_raw /* [nimg] */, double *MFL, double *MFR);
 /* sweep-kernel launches issued by the last deff_sweeps()/deff_solve() and the sweeps one
  * temporally blocked launch performs (1 for the single-sweep kernels) */
 int deff_last_launches(const deff_ctx *ctx, int64_t *launches, int *sweeps_per_pass);

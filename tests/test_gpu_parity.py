@@ -182,6 +182,91 @@ def test_temporal_blocking_zero_diffusivity_guard(pkg, oracle, img00000):
         assert_field(s.get_field(), want)
 
 
+# ------------------------------------------------------------------- batches
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("shape,B", [((130, 70), 5), ((64, 9), 3), ((33, 17), 4), ((256, 128), 2)])
+def test_batch_sweeps_equal_single_image_runs(pkg, oracle, shape, B, kernel):
+    """A stacked batch is swept as one domain; every image must come out exactly as if it had
+    been swept alone (the zero-flux top/bottom walls keep the images uncoupled)."""
+    nx, ny = shape
+    rng = np.random.default_rng(B * 100 + nx)
+    pix = np.stack([rand_mask(rng, nx, ny, 0.4 + 0.05 * k) for k in range(B)])
+    x0 = rng.random((B, ny, nx))
+    with pkg.Solver(nx, ny, kernel=kernel, nimg=B) as s:
+        s.set_tuning("tb_LY", 16)
+        s.set_image(pix)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        A, b = s.get_system()
+        s.set_field(x0.reshape(B * ny, nx))
+        s.sweeps(11)
+        got = s.get_field().reshape(B, ny, nx)
+        deffs, MFL, MFR = s.flux()
+    for k in range(B):
+        D = oracle.fill_D_2phase(pix[k], 1.0, 1e-3)
+        Ao, bo = oracle.discretize(D, 0.0, 1.0)
+        n = nx * ny
+        assert np.array_equal(A[k * n:(k + 1) * n], Ao) and np.array_equal(b[k * n:(k + 1) * n], bo)
+        want = oracle.sweeps(Ao, bo, x0[k], 11)
+        assert_field(got[k], want)
+        d, l, r = oracle.flux_deff(want, D, 0.0, 1.0)
+        assert deffs[k] == d and np.array_equal(MFL[k * ny:(k + 1) * ny], l)
+
+
+@pytest.mark.parametrize("kernel", ["matfree_tb", "explicit", "scalar"])
+def test_batch_solve_each_image_stops_by_its_own_rule(pkg, oracle, kernel):
+    """Images of one batch converge after different numbers of checks; each must report the
+    sweep count, Deff, conv and field of a one-image run of the reference loop."""
+    nx, ny, B = 64, 48, 5
+    rng = np.random.default_rng(42)
+    pix = np.stack([rand_mask(rng, nx, ny, p) for p in (0.3, 0.5, 0.7, 0.9, 0.5)])
+    pix[3] = 255
+    pix[3, :10, :] = 0                      # parallel stripes: exact after the first interval
+    with pkg.Solver(nx, ny, kernel=kernel, nimg=B) as s:
+        s.set_image(pix)
+        s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        res = s.solve(2e-3, 5000, check_every=100)
+        got = s.get_field().reshape(B, ny, nx)
+        # warm start of the whole batch from the frozen fields
+        res2 = s.solve(5e-4, 300, check_every=100)
+        got2 = s.get_field().reshape(B, ny, nx)
+    its = set()
+    for k in range(B):
+        D = oracle.fill_D_2phase(pix[k], 1.0, 1e-2)
+        A, b = oracle.discretize(D, 0.0, 1.0)
+        it, deff, conv, x, MFL, MFR = oracle.jacobi(A, b, oracle.linear_guess(nx, ny, 0.0, 1.0), D, 0.0, 1.0,
+                                                    2e-3, 5000, check_every=100)
+        its.add(it)
+        r = res[k]
+        assert (r.iters, r.deff_raw, r.conv) == (it, deff, conv), (k, r, it, deff, conv)
+        assert np.array_equal(r.MFL, MFL) and np.array_equal(r.MFR, MFR)
+        assert_field(got[k], x)
+        it2, deff2, conv2, x2, _, _ = oracle.jacobi(A, b, x, D, 0.0, 1.0, 5e-4, 300, check_every=100)
+        assert (res2[k].iters, res2[k].deff_raw, res2[k].conv) == (it2, deff2, conv2)
+        assert_field(got2[k], x2)
+    assert len(its) >= 3, its                # the batch really did split up
+
+
+def test_batch_synthetic_first_check_at_1024(pkg, oracle, recorded):
+    """4 stacked 1024^2 synthetic images = images 0..3 of the generator; image 0 must give the
+    reference's recorded first-check Deff, the others the oracle's."""
+    B, n = 4, 1024
+    with pkg.Solver(n, n, nimg=B) as s:
+        s.synth_image(12345, 0)
+        pix = s.get_image().reshape(B, n, n)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        res = s.solve(1e-6, 1)
+    assert res[0].deff_raw == recorded["synthetic_first_check_deff"]["1024"]
+    for k in range(B):
+        assert np.array_equal(pix[k], oracle.synth_mask(n, n, 12345, k))
+    D = oracle.fill_D_2phase(pix[2], 1.0, 1e-3)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    d, _, _ = oracle.flux_deff(oracle.sweeps(A, b, oracle.linear_guess(n, n, 0.0, 1.0), 1), D, 0.0, 1.0)
+    assert res[2].deff_raw == d
+
+
 def test_host_assembled_system_drop_in(pkg, oracle):
     """The reference's own arrays (A AoS, b, D) go in unchanged: set_system + solve."""
     rng = np.random.default_rng(11)

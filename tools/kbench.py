@@ -24,21 +24,22 @@ def main():
         solvers = []
         for var in args.variants.split(","):
             parts = var.split(":")
-            s = pkg.Solver(n, n, kernel=parts[0])
-            for kv in parts[1:]:
-                k, v = kv.split("=")
+            kvs = dict(kv.split("=") for kv in parts[1:])
+            nimg = int(kvs.pop("nimg", 1))
+            s = pkg.Solver(n, n, kernel=parts[0], nimg=nimg)
+            for k, v in kvs.items():
                 s.set_tuning(k, int(v))
             s.synth_image(12345, 0)
             s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
             s.init_linear(0.0, 1.0)
             s.sweeps(10)
-            solvers.append((var, s, []))
+            solvers.append((var, s, [], nimg))
         for _ in range(args.rounds):
-            for var, s, times in solvers:
+            for var, s, times, nimg in solvers:
                 times.append(s.sweeps(args.sweeps) / args.sweeps)   # ms per sweep
-        for var, s, times in solvers:
+        for var, s, times, nimg in solvers:
             best, med = min(times), sorted(times)[len(times) // 2]
-            rate = n * n / (med * 1e-3) / 1e6
+            rate = nimg * n * n / (med * 1e-3) / 1e6
             print(f"n={n:6d} {var:40s} med {med*1e3:9.2f} us  min {best*1e3:9.2f} us  "
                   f"{rate:10.0f} Mcells*iter/s  {rate*64/1e3:8.0f} GB/s@64B  frac {rate*64/8e6:.3f}", flush=True)
             s.close()
