@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=4096)
-    ap.add_argument("--sweeps-per-step", type=int, default=1000)
+    ap.add_argument("--sweeps-per-step", type=int, default=1200)   # multiple of every T
     ap.add_argument("--kernel", default="auto", choices=["auto", "explicit", "scalar", "matfree", "matfree_tb"])
     ap.add_argument("--omega", type=float, default=2.0 / 3.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -19,7 +19,7 @@ SYMBOLS = [
     "deff_version", "deff_last_error", "deff_error_string", "deff_device_count",
     "deff_create", "deff_create_batch", "deff_batch_size", "deff_destroy", "deff_mesh", "deff_set_kernel", "deff_get_kernel",
     "deff_set_tuning", "deff_set_image", "deff_synth_image", "deff_get_image",
-    "deff_assemble_2phase", "deff_assemble_from_D", "deff_set_system", "deff_get_system",
+    "deff_assemble_2phase", "deff_assemble_3phase", "deff_flood_fill", "deff_assemble_from_D", "deff_set_system", "deff_get_system",
     "deff_init_linear", "deff_set_field", "deff_get_field", "deff_solve", "deff_solve_batch", "deff_sweeps",
     "deff_flux", "deff_set_progress", "deff_last_launches", "deff_device_field", "deff_synchronize",
 ]
@@ -71,6 +71,10 @@ def load():
     L.deff_synth_image.argtypes = [ctx, C.c_uint64, C.c_uint64]
     L.deff_get_image.argtypes = [ctx, _u8p]
     L.deff_assemble_2phase.argtypes = [ctx, C.c_double, C.c_double, C.c_double, C.c_double]
+    L.deff_assemble_3phase.argtypes = [ctx, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_double,
+                                       C.c_double]
+    L.deff_flood_fill.argtypes = [np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS"), C.c_int, C.c_int,
+                                  C.POINTER(C.c_int)]
     L.deff_assemble_from_D.argtypes = [ctx, _dp, C.c_void_p, C.c_double, C.c_double]
     L.deff_set_system.argtypes = [ctx, _dp, _dp, C.c_void_p, C.c_double, C.c_double]
     L.deff_get_system.argtypes = [ctx, _dp, _dp]

@@ -29,11 +29,42 @@ def solve_image(solver, pix, Ds, Df, CL, CR, tol, max_iter, omega=2.0 / 3.0):
     return r.deff_raw / Df, r.conv, r.iters, r.loop_ms
 
 
+def solve_image_3phase(solver, pix, Ds, Df, Dg, CL, CR, tol, max_iter, omega=2.0 / 3.0):
+    """SingleSim3Phase / BatchSim3Phase (Deff2D.cuh:1316-1633, preCond = true cuh:1443): Grid from
+    pixels > 200 + FloodFill; the gas diffusivity is ramped 10, 100, ... (< Dg) with the tolerance
+    x10 and MAX_ITER 1e6 (the JacobiGPUPreCond stages, cuh:1486-1549), each stage warm-started from
+    the previous field, which never leaves the device; then the real Dg with the user's tolerance
+    (cuh:1553-1596).  Returns dict(deff, conv, stage_sweeps, path_flag, loop_ms)."""
+    from .solver import flood_fill
+    grid, path = flood_fill((np.asarray(pix) > 200).astype(np.uint32))
+    solver.set_image(pix)
+    solver.init_linear(CL, CR)
+    stages, ms = [], 0.0
+    g = 10.0
+    while g < Dg:
+        solver.assemble_3phase(Ds, Df, g, CL, CR, grid)
+        r = solver.solve(tol * 10, 1000000, omega=omega)
+        stages.append(r.iters)
+        ms += r.loop_ms
+        g = g * 10
+    solver.assemble_3phase(Ds, Df, Dg, CL, CR, grid)
+    r = solver.solve(tol, max_iter, omega=omega)
+    stages.append(r.iters)
+    return dict(deff=r.deff_raw / Df, conv=r.conv, stage_sweeps=stages, path_flag=path, loop_ms=ms + r.loop_ms)
+
+
+def path_flag_2phase(pix):
+    """PathFlag column of BatchSim: FloodFill on Grid = (pixel > 150), cuh:1919-1932."""
+    from .solver import flood_fill
+    return flood_fill((np.asarray(pix) > 150).astype(np.uint32))[1]
+
+
 def run_batch(solver, load_image, num_images, Ds, Df, CL, CR, tol, max_iter, rank=0, world=1, dist=None,
-              device=None):
+              device=None, path_flag=None):
     """Solve images rank, rank+world, ... and gather the table on rank 0.
 
     load_image(k) -> uint8 (H, W) pixels of image k (stb-decoded JPEG or synthetic).
+    path_flag: callable(pix) -> bool for the PathFlag column (path_flag_2phase), None = -1.
     Returns the (num_images, 9) table on rank 0, None elsewhere.
     """
     mine = shard(num_images, rank, world)
@@ -42,8 +73,8 @@ def run_batch(solver, load_image, num_images, Ds, Df, CL, CR, tol, max_iter, ran
         pix = load_image(k)
         porosity = float(np.count_nonzero(pix < 150)) / pix.size            # calcPorosity cuh:383-408
         deff, conv, iters, ms = solve_image(solver, pix, Ds, Df, CL, CR, tol, max_iter)
-        rows[slot] = (k, porosity, -1.0,          # PathFlag needs FloodFill (cuh:557-713): not computed here
-                      deff, ms / 1000.0, pix.size, conv, Ds, Df)
+        path = path_flag(pix) if path_flag is not None else -1.0
+        rows[slot] = (k, porosity, float(path), deff, ms / 1000.0, pix.size, conv, Ds, Df)
     if world == 1 or dist is None:
         return rows
     import torch

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/deff_amd.h"
+#include "flood_fill.hpp"
 #include "fvm_row.hpp"
 #include "kernels_setup.hpp"
 #include "kernels_sweep.hpp"
@@ -485,6 +486,47 @@ static int explicit_from_image(deff_ctx *c)
     HIP_TRY(hipGetLastError());
     c->have_explicit = true;
     c->c0_omega = NAN;
+    return DEFF_OK;
+}
+
+// 3-phase system (SingleSim3Phase cuh:1509-1535 / cuh:1558-1586): D from the three pixel
+// classes on the device, then DiscretizeMatrix2D_ImpSolid with the caller's Grid (the output of
+// deff_flood_fill on `pixel > 200`), or plain DiscretizeMatrix2D when Grid is NULL.  Explicit
+// coefficient planes: identity rows and zero-diffusivity links need the guarded general kernel.
+extern "C" int deff_assemble_3phase(deff_ctx *c, double Ds, double Df, double Dg, const unsigned int *Grid,
+                                    double CL, double CR)
+{
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    if (!c->have_image) return fail(DEFF_ESTATE, "deff_assemble_3phase needs an image");
+    TRY(use_device(c));
+    TRY(ensure_explicit(c));
+    TRY(ensure_walls(c));
+    const size_t bytes = sizeof(double) * c->n + (Grid ? sizeof(unsigned int) * c->n : 0);
+    TRY(ensure_scratch(c, bytes));
+    double *dD = (double *)c->scratch;
+    unsigned int *dG = Grid ? (unsigned int *)((char *)c->scratch + sizeof(double) * c->n) : nullptr;
+    if (Grid) HIP_TRY(hipMemcpyAsync(dG, Grid, sizeof(unsigned int) * c->n, hipMemcpyHostToDevice, c->stream));
+    c->CL = CL; c->CR = CR;
+    hipLaunchKernelGGL(k_fill_D_3phase, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->W, c->ampX,
+                       c->ampY, c->nx, c->ny, c->rows, Df, Ds, Dg, dD);
+    hipLaunchKernelGGL(k_assemble_from_D, dim3(grid_for(c->n)), dim3(256), 0, c->stream, dD, dG, c->nx,
+                       c->ny, c->rows, c->dx, c->dy, CL, CR, soa_of(c));
+    hipLaunchKernelGGL(k_wall_D_from_D, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, dD, c->nx,
+                       c->rows, c->Dl, c->Dr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));        // Grid may be freed by the caller
+    c->have_explicit = true; c->c0_omega = NAN; c->have_walls = true;
+    c->have_matfree = false;
+    return DEFF_OK;
+}
+
+// FloodFill, cuh:557-713 (host, see flood_fill.hpp).  Grid: 1 = solid on entry; unreachable
+// non-solid cells are set to 2; *path_flag receives PathFlag.
+extern "C" int deff_flood_fill(unsigned int *Grid, int nx, int ny, int *path_flag)
+{
+    if (!Grid || nx < 1 || ny < 1) return fail(DEFF_EINVAL, "bad flood-fill arguments");
+    const int flag = flood_fill(Grid, nx, ny);
+    if (path_flag) *path_flag = flag;
     return DEFF_OK;
 }
 
@@ -959,6 +1001,7 @@ extern "C" int deff_solve_batch(deff_ctx *c, double omega, double tol, int64_t m
     TRY(plan_sweeps(c, omega, &pl));
     if (!c->have_walls) return fail(DEFF_ESTATE, "wall diffusivities unknown (needed for Deff)");
     TRY(consolidate(c));                                             // x is in/out: warm start from x[cur]
+    reset_batch_state(c);                                            // every image iterates again
 
     const int B = c->nimg;
     std::vector<double> deffNew(B, 1.0), deffOld(B, 5.0), change(B, 100.0), conv(B, 0.0);   // cuh:1171-1173

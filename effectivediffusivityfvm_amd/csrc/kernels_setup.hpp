@@ -58,6 +58,20 @@ __global__ void k_fill_D_2phase(const uint8_t *__restrict__ pix, int W, int ampX
     }
 }
 
+// 3-phase D fill, cuh:1518-1529: pixel > 200 -> solid, < 50 -> gas, otherwise fluid.
+__global__ void k_fill_D_3phase(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
+                                int nx, int ny, int rows, double DCF, double DCS, double DCG,
+                                double *__restrict__ D)
+{
+    const size_t n = (size_t)nx * rows;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
+         p += (size_t)gridDim.x * blockDim.x) {
+        int i = (int)(p / nx), j = (int)(p % nx);
+        const uint8_t v = cell_pixel(pix, W, ampX, ampY, ny, i, j);
+        D[p] = (v > 200) ? DCS : (v < 50 ? DCG : DCF);
+    }
+}
+
 // Diffusivity of the first and last cell of every row, for the wall fluxes
 // (cuh:1256-1257 read D[j*nx] and D[(j+1)*nx-1]).
 __global__ void k_wall_D_2phase(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,

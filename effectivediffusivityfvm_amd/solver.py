@@ -87,6 +87,14 @@ class Solver:
     def assemble_2phase(self, Ds, Df, CL, CR):
         check(self._L.deff_assemble_2phase(self._ctx, Ds, Df, CL, CR))
 
+    def assemble_3phase(self, Ds, Df, Dg, CL, CR, grid=None):
+        g = None
+        if grid is not None:
+            grid = np.ascontiguousarray(grid, dtype=np.uint32)
+            assert grid.size == self.nx * self.rows
+            g = grid.ctypes.data_as(C.c_void_p)
+        check(self._L.deff_assemble_3phase(self._ctx, Ds, Df, Dg, g, CL, CR))
+
     def assemble_from_D(self, D, CL, CR, grid=None):
         D = np.ascontiguousarray(D, dtype=np.float64)
         g = None
@@ -181,4 +189,14 @@ class Solver:
         check(self._L.deff_synchronize(self._ctx))
 
 
-__all__ = ["Solver", "SolveResult", "DeffError", "OMEGA_REFERENCE"]
+def flood_fill(grid):
+    """FloodFill (Deff2D.cuh:557-713): grid (ny, nx) with 1 = solid -> (grid with unreachable
+    pore cells = 2, PathFlag).  Host function of the library; needs no GPU."""
+    g = np.array(grid, dtype=np.uint32, order="C", copy=True)
+    ny, nx = g.shape
+    flag = C.c_int()
+    check(_capi.load().deff_flood_fill(g, nx, ny, C.byref(flag)))
+    return g, bool(flag.value)
+
+
+__all__ = ["Solver", "flood_fill", "SolveResult", "DeffError", "OMEGA_REFERENCE"]

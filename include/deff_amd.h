@@ -91,6 +91,13 @@ int deff_assemble_2phase(deff_ctx *ctx, double Ds, double Df, double CL, double 
  * Grid[n] selects DiscretizeMatrix2D_ImpSolid cuh:715-812 semantics (NULL = plain) */
 int deff_assemble_from_D(deff_ctx *ctx, const double *D, const unsigned int *Grid,
                          double CL, double CR);
+/* 3-phase path (SingleSim3Phase cuh:1509-1586): D from pixels (> 200 solid, < 50 gas, else
+ * fluid, cuh:1518-1529) on the device + DiscretizeMatrix2D_ImpSolid with Grid (NULL = plain) */
+int deff_assemble_3phase(deff_ctx *ctx, double Ds, double Df, double Dg, const unsigned int *Grid,
+                         double CL, double CR);
+/* FloodFill cuh:557-713 on the host, linear time: Grid[n] (1 = solid) gets 2 where the pore
+ * space is not connected to the left wall; *path_flag = PathFlag.  Needs no context. */
+int deff_flood_fill(unsigned int *Grid, int nx, int ny, int *path_flag);
 /* host-assembled system as the reference passes it to JacobiGPU (cuh:1163):
  * A[n*5] AoS, b[n], D[n] (only its first and last column are read, cuh:1256-1257) */
 int deff_set_system(deff_ctx *ctx, const double *A, const double *b, const double *D,

@@ -301,3 +301,62 @@ long oracle_jacobi(const double *A, const double *b, double *x, double *tmp,
     *conv_out = conv;
     return iter;
 }
+
+/* ------------------------------------------------ connectivity / 3-phase */
+
+/* cuh:557-713 FloodFill.  4-connected fill of the non-solid cells (Grid != 1)
+ * from the left column, periodic in the row direction (cuh:641-664), not in
+ * the column direction.  Cells never reached get Grid = 2 (cuh:699-706).
+ * Two reference behaviours are kept on purpose:
+ *   - the right-column seeding test reads `Domain[indexR == -1]`, i.e.
+ *     Domain[0] (cuh:601): once the loop has handled row 0, Domain[0] is 0
+ *     iff the top-left cell is not solid, so the whole right column is seeded
+ *     (solid cells included) iff the TOP-LEFT cell is solid, else never;
+ *   - PathFlag is raised whenever a popped cell lies in the last column
+ *     (cuh:619-621), which includes those seeds.
+ * The reference pops from an ordered std::set; the set of reached cells does
+ * not depend on the order, so a plain stack is used here.
+ * Returns the PathFlag (0/1); Grid is updated in place. */
+int oracle_floodfill(unsigned int *Grid, int nx, int ny)
+{
+    const long n = (long)nx * ny;
+    int *Domain = (int *)malloc(sizeof(int) * (size_t)n);
+    long *stack = (long *)malloc(sizeof(long) * (size_t)(n + 2 * (long)ny + 4));
+    long top = 0;
+    int path = 0;
+    for (long p = 0; p < n; p++) Domain[p] = (Grid[p] == 1) ? 1 : -1;
+    for (int row = 0; row < ny; row++) {
+        long iL = (long)row * nx, iR = (long)(row + 1) * nx - 1;
+        if (Domain[iL] == -1) { Domain[iL] = 0; stack[top++] = iL; }
+        if (Domain[0]) { Domain[iR] = 0; stack[top++] = iR; }          /* cuh:601 as written */
+    }
+    while (top > 0) {
+        long p = stack[--top];
+        int row = (int)(p / nx), col = (int)(p % nx);
+        if (col == nx - 1) path = 1;
+        int rn = (row == 0) ? ny - 1 : row - 1;
+        int rs = (row == ny - 1) ? 0 : row + 1;
+        long q;
+        q = (long)rn * nx + col; if (Domain[q] == -1) { Domain[q] = 0; stack[top++] = q; }
+        q = (long)rs * nx + col; if (Domain[q] == -1) { Domain[q] = 0; stack[top++] = q; }
+        if (col != 0)      { q = p - 1; if (Domain[q] == -1) { Domain[q] = 0; stack[top++] = q; } }
+        if (col != nx - 1) { q = p + 1; if (Domain[q] == -1) { Domain[q] = 0; stack[top++] = q; } }
+    }
+    for (long p = 0; p < n; p++) if (Domain[p] == -1) Grid[p] = 2;
+    free(Domain);
+    free(stack);
+    return path;
+}
+
+/* cuh:411-448 calcFracts3D: solid / liquid volume fractions by exact comparison
+ * of D with the phase diffusivities, accumulated as repeated += 1/total. */
+void oracle_fracts_3d(const double *D, long n, double DCS, double DCF, double *SVF, double *LVF)
+{
+    double total = (double)n, s = 0, l = 0;
+    for (long p = 0; p < n; p++) {
+        if (D[p] == DCS) s += 1.0 / total;
+        else if (D[p] == DCF) l += 1.0 / total;
+    }
+    *SVF = s;
+    *LVF = l;
+}

@@ -66,6 +66,11 @@ def lib(flavour=None):
                                 C.c_double, C.c_long, C.c_long, _dp, _dp, _dp, C.c_int, C.c_double,
                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.oracle_jacobi.restype = C.c_long
+    L.oracle_floodfill.argtypes = [_u32p, C.c_int, C.c_int]
+    L.oracle_floodfill.restype = C.c_int
+    L.oracle_fracts_3d.argtypes = [_dp, C.c_long, C.c_double, C.c_double, C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double)]
+    L.oracle_fracts_3d.restype = None
     if flavour is None:
         _LIB = L
     _LIBS[flavour] = L
@@ -150,3 +155,44 @@ def jacobi(A, b, x0, D, CL, CR, tol, max_iter, check_every=10000, kernel=0, omeg
                              np.ascontiguousarray(D), MFL, MFR, kernel, omega,
                              C.byref(deff), C.byref(conv))
     return it, deff.value, conv.value, x, MFL, MFR
+
+
+def floodfill(grid):
+    """grid: (ny, nx) uint32 with 1 = solid; returns (grid with unreachable cells = 2, PathFlag)."""
+    g = np.array(grid, dtype=np.uint32, order="C", copy=True)
+    ny, nx = g.shape
+    flag = lib().oracle_floodfill(g, nx, ny)
+    return g, bool(flag)
+
+
+def fracts_3d(D, DCS, DCF):
+    s = C.c_double()
+    l = C.c_double()
+    D = np.ascontiguousarray(D)
+    lib().oracle_fracts_3d(D, D.size, DCS, DCF, C.byref(s), C.byref(l))
+    return s.value, l.value
+
+
+def solve_3phase(pix, DCS, DCF, DCG, CL, CR, tol, max_iter, flavour=None):
+    """SingleSim3Phase / BatchSim3Phase, cuh:1316-1633 (preCond = true, cuh:1443), on the oracle:
+    Grid from pixels > 200 + FloodFill; gas diffusivity ramped 10, 100, ... < DCG with
+    tolerance x10 and MAX_ITER 1e6 (JacobiGPUPreCond), each stage warm-started; then the real
+    DCG with the user's tolerance (JacobiGPU).  Returns dict(stage_sweeps, deff, conv, SVF, LVF,
+    field, grid, path)."""
+    ny, nx = pix.shape
+    grid, path = floodfill((pix > 200).astype(np.uint32))
+    x = linear_guess(nx, ny, CL, CR)
+    stages = []
+    g = 10.0
+    while g < DCG:                                   # cuh:1492
+        D = fill_D_3phase(pix, DCF, DCS, g)
+        A, b = discretize(D, CL, CR, grid=grid)
+        it, _, _, x, _, _ = jacobi(A, b, x, D, CL, CR, tol * 10, 1000000, flavour=flavour)
+        stages.append(it)
+        g = g * 10
+    D = fill_D_3phase(pix, DCF, DCS, DCG)
+    svf, lvf = fracts_3d(D, DCS, DCF)
+    A, b = discretize(D, CL, CR, grid=grid)
+    it, deff, conv, x, _, _ = jacobi(A, b, x, D, CL, CR, tol, max_iter, flavour=flavour)
+    stages.append(it)
+    return dict(stage_sweeps=stages, deff=deff / DCF, conv=conv, SVF=svf, LVF=lvf, field=x, grid=grid, path=path)

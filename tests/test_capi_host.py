@@ -72,3 +72,23 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle_binding" not in text and "libdeff_oracle" not in text and "deff_oracle" not in text, f
+
+
+def test_flood_fill_host_function_matches_oracle(capi, oracle, img00000, recorded):
+    """deff_flood_fill is host code (no GPU): same Grid and PathFlag as the oracle's restatement
+    of the reference's FloodFill, including the right-column seeding quirk."""
+    import numpy as np
+    import effectivediffusivityfvm_amd as pkg
+    rng = np.random.default_rng(1)
+    for _ in range(300):
+        ny, nx = rng.integers(2, 16), rng.integers(2, 16)
+        g = (rng.random((ny, nx)) < rng.uniform(0.1, 0.9)).astype(np.uint32)
+        a, pa = oracle.floodfill(g)
+        b, pb = pkg.flood_fill(g)
+        assert np.array_equal(a, b) and pa == pb
+    for thr in (150, 200):
+        a, pa = oracle.floodfill((img00000 > thr).astype(np.uint32))
+        b, pb = pkg.flood_fill((img00000 > thr).astype(np.uint32))
+        assert np.array_equal(a, b) and pa == pb
+    assert pkg.flood_fill((img00000 > 150).astype(np.uint32))[1] == bool(
+        recorded["img00000_3phase_as_shipped"]["PathFlag_2phase"])

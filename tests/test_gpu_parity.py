@@ -182,6 +182,48 @@ def test_temporal_blocking_zero_diffusivity_guard(pkg, oracle, img00000):
         assert_field(s.get_field(), want)
 
 
+def test_img00000_3phase_as_shipped(pkg, oracle, recorded, img00000):
+    """The configuration the reference's shipped input.txt selects: 3 phases, Ds = 0, Dg = 1237500,
+    DCG continuation (6 JacobiGPUPreCond stages + JacobiGPU), FloodFill, ImpSolid rows.  Every
+    recorded number of the reference is reproduced: stage sweep counts, Deff, conv."""
+    from effectivediffusivityfvm_amd import batch
+    rec = recorded["img00000_3phase_as_shipped"]
+    o = rec["options"]
+    with pkg.Solver(128, 128) as s:
+        r = batch.solve_image_3phase(s, img00000, o["Ds"], o["Df"], o["Dg"], o["CL"], o["CR"], o["tol"],
+                                     o["max_iter"])
+        field = s.get_field()
+    assert r["stage_sweeps"] == rec["stage_sweeps"]
+    assert abs(r["deff"] - rec["deff"]) <= DEFF_TOL * rec["deff"]
+    assert r["deff"] == rec["deff"] and r["conv"] == rec["conv"]
+    with np.errstate(all="ignore"):
+        want = oracle.solve_3phase(img00000, o["Ds"], o["Df"], o["Dg"], o["CL"], o["CR"], o["tol"], o["max_iter"])
+    assert_field(field, want["field"])
+    solid = img00000 > 200
+    assert np.all(np.abs(field[solid]) < 1e-300)          # impermeable solid decays to 0 (x <- x/3 per sweep)
+
+
+def test_3phase_assembly_with_grid_and_amplification(pkg, oracle):
+    rng = np.random.default_rng(9)
+    pix = rng.choice(np.array([0, 30, 120, 150, 199, 201, 255], dtype=np.uint8), size=(9, 11))
+    grid, _ = oracle.floodfill((pix > 200).astype(np.uint32))
+    D = oracle.fill_D_3phase(pix, 1.0, 0.0, 50.0)
+    with np.errstate(all="ignore"):
+        A, b = oracle.discretize(D, 0.2, 0.9, grid=grid)
+    with pkg.Solver(11, 9) as s:
+        s.set_image(pix)
+        s.assemble_3phase(0.0, 1.0, 50.0, 0.2, 0.9, grid)
+        Ag, bg = s.get_system()
+    assert np.array_equal(Ag, A, equal_nan=True) and np.array_equal(bg, b, equal_nan=True)
+    D2 = oracle.fill_D_3phase(pix, 1.0, 0.5, 50.0, ampX=2, ampY=3)
+    A2, b2 = oracle.discretize(D2, 0.0, 1.0)
+    with pkg.Solver(22, 27) as s:
+        s.set_image(pix, 2, 3)
+        s.assemble_3phase(0.5, 1.0, 50.0, 0.0, 1.0, None)
+        Ag, bg = s.get_system()
+    assert np.array_equal(Ag, A2) and np.array_equal(bg, b2)
+
+
 # ------------------------------------------------------------------- batches
 
 @pytest.mark.parametrize("kernel", KERNELS)

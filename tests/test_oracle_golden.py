@@ -154,3 +154,41 @@ def test_mesh_amplification_and_guess(oracle):
     assert np.all(D[:2, :3] == 2.0) and np.all(D[:2, 3:] == 0.5) and np.all(D[2:, :3] == 0.5)
     x = oracle.linear_guess(6, 4, 0.25, 0.75)
     assert x[0, 0] == 0.25 and np.allclose(x[:, 3], 0.5) and np.all(np.diff(x, axis=0) == 0)
+
+
+def test_img00000_3phase_as_shipped(oracle, recorded, img00000):
+    """The configuration the reference's shipped input.txt selects (3 phases, Ds = 0, DCG
+    continuation): FloodFill with its seeding quirk, DiscretizeMatrix2D_ImpSolid,
+    JacobiGPUPreCond stages and the final JacobiGPU -- every recorded number reproduced."""
+    rec = recorded["img00000_3phase_as_shipped"]
+    o = rec["options"]
+    with np.errstate(all="ignore"):
+        r = oracle.solve_3phase(img00000, o["Ds"], o["Df"], o["Dg"], o["CL"], o["CR"], o["tol"], o["max_iter"])
+    assert r["stage_sweeps"] == rec["stage_sweeps"] and sum(r["stage_sweeps"]) == rec["total_sweeps"]
+    assert r["deff"] == rec["deff"]
+    assert r["conv"] == rec["conv"]
+    assert r["SVF"] == rec["SVF"] and r["LVF"] == rec["LVF"]
+
+
+def test_floodfill_semantics(oracle):
+    """Periodic in rows, not in columns; unreachable non-solid cells become 2; the right
+    column is seeded iff the top-left cell is solid (reference quirk, cuh:601)."""
+    g = np.ones((5, 6), dtype=np.uint32)
+    g[2, :] = 0                       # an open channel in row 2 ...
+    g[0, 3] = 0                       # ... an isolated pocket ...
+    g[4, 0] = 0                       # ... and a left-wall cell that wraps to row 0 col 0 (solid)
+    out, path = oracle.floodfill(g)
+    assert path                      # top-left solid: right column seeded, PathFlag raised
+    assert out[0, 3] == 2 and out[2, 2] == 0 and out[4, 0] == 0
+    g2 = g.copy()
+    g2[0, 0] = 0                      # top-left fluid: no right-column seeding
+    g2[2, 3] = 1                      # break the channel
+    out2, path2 = oracle.floodfill(g2)
+    assert not path2
+    assert out2[2, 4] == 2 and out2[2, 5] == 2 and out2[2, 1] == 0
+    g3 = np.ones((4, 4), dtype=np.uint32)
+    g3[0, 0] = 0
+    g3[3, 0] = 0                      # reached through the periodic wrap from (0,0)
+    g3[3, 1] = 0
+    out3, _ = oracle.floodfill(g3)
+    assert out3[3, 1] == 0
