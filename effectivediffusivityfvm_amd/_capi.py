@@ -21,6 +21,10 @@ SYMBOLS = [
     "deff_set_tuning", "deff_set_image", "deff_synth_image", "deff_get_image",
     "deff_assemble_2phase", "deff_assemble_3phase", "deff_flood_fill", "deff_assemble_from_D", "deff_set_system", "deff_get_system",
     "deff_init_linear", "deff_set_field", "deff_get_field", "deff_solve", "deff_solve_batch", "deff_sweeps",
+    "deff_slab_group_create", "deff_slab_group_destroy", "deff_slab_group_layout", "deff_slab_group_set_tuning",
+    "deff_slab_group_set_image", "deff_slab_group_synth_image", "deff_slab_group_assemble_2phase",
+    "deff_slab_group_init_linear", "deff_slab_group_set_field", "deff_slab_group_get_field",
+    "deff_slab_group_sweeps", "deff_slab_group_flux", "deff_slab_group_solve",
     "deff_flux", "deff_set_progress", "deff_last_launches", "deff_device_field", "deff_synchronize",
 ]
 
@@ -89,6 +93,21 @@ def load():
     L.deff_flux.argtypes = [ctx, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
     L.deff_set_progress.argtypes = [ctx, PROGRESS_FN, C.c_void_p]
     L.deff_last_launches.argtypes = [ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+    ip = C.POINTER(C.c_int)
+    L.deff_slab_group_create.argtypes = [C.c_int, ip, C.c_int, C.c_int, C.POINTER(ctx)]
+    L.deff_slab_group_destroy.argtypes = [ctx]
+    L.deff_slab_group_layout.argtypes = [ctx, ip, ip]
+    L.deff_slab_group_set_tuning.argtypes = [ctx, C.c_char_p, C.c_int]
+    L.deff_slab_group_set_image.argtypes = [ctx, _u8p]
+    L.deff_slab_group_synth_image.argtypes = [ctx, C.c_uint64, C.c_uint64]
+    L.deff_slab_group_assemble_2phase.argtypes = [ctx, C.c_double, C.c_double, C.c_double, C.c_double]
+    L.deff_slab_group_init_linear.argtypes = [ctx, C.c_double, C.c_double]
+    L.deff_slab_group_set_field.argtypes = [ctx, _dp]
+    L.deff_slab_group_get_field.argtypes = [ctx, _dp]
+    L.deff_slab_group_sweeps.argtypes = [ctx, C.c_int64, C.c_double, C.POINTER(C.c_float)]
+    L.deff_slab_group_flux.argtypes = [ctx, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
+    L.deff_slab_group_solve.argtypes = [ctx, C.c_double, C.c_double, C.c_int64, C.c_int64, C.POINTER(Result),
+                                        C.c_void_p, C.c_void_p]
     L.deff_device_field.argtypes = [ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.deff_synchronize.argtypes = [ctx]
     for name in SYMBOLS:

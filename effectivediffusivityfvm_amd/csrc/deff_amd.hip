@@ -66,6 +66,11 @@ struct deff_ctx {
     size_t n_img = 0;               // cells per image
     size_t n = 0;                   // cells in the stack
     double dx = 0, dy = 0;
+    // Row slab of a taller image (multi-GPU split of one image): the arrays hold
+    // `halo` rows above and below the `own_h` rows this context updates; array row li is mesh row
+    // li - dom_lo of a mesh_ny-row mesh.  Plain contexts: dom_lo = 0, mesh_ny = own_h = ny, halo = 0.
+    bool slab = false;
+    int dom_lo = 0, mesh_ny = 0, own_lo = 0, own_h = 0, halo = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -228,6 +233,7 @@ extern "C" int deff_create_batch(int device, int nx, int ny, int nimg, deff_ctx 
     c->nx = nx; c->ny = ny; c->nimg = nimg; c->rows = nimg * ny;
     c->n_img = (size_t)nx * ny; c->n = c->n_img * nimg;
     c->active_h.assign(nimg, 1); c->buf_of.assign(nimg, 0);
+    c->mesh_ny = ny; c->own_h = ny;
     c->dx = 1.0 / nx;           // cuh:1910-1911: the domain is always the unit square
     c->dy = 1.0 / ny;
     int rc = DEFF_OK;
@@ -457,7 +463,7 @@ extern "C" int deff_assemble_2phase(deff_ctx *c, double Ds, double Df, double CL
     // matrix-free form: 1 byte per cell + lookup tables
     TRY(dev_alloc(&c->code, c->n));
     hipLaunchKernelGGL(k_phase_codes, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->W, c->ampX,
-                       c->ampY, c->nx, c->ny, c->rows, c->code);
+                       c->ampY, c->nx, c->ny, c->rows, c->dom_lo, c->mesh_ny, c->code);
     HIP_TRY(hipGetLastError());
     build_lut_rows(c, Ds, Df, CL, CR);
     c->have_matfree = true;
@@ -710,6 +716,7 @@ struct SweepPlan {
     int rows = 0, cpi = 0, gx = 0, gy = 0, blocks = 0;   // single-sweep kernels (cpi: row tiles per image)
     // temporally blocked kernel
     int T = 0, CPL = 2, LY = 0, tcpi = 0, ntx = 0, tgx = 0, tgy = 0, tblocks = 0;
+    int T_override = 0;                                   // slab mode plans a T = 1 pass for remainders
     bool guard = false;
     // the reference's non-zero link test matters only when a phase cannot diffuse
     static bool guard_probe(const deff_ctx *c)
@@ -733,6 +740,7 @@ static int tb_occ(int *per_cu)
     do {                                                                                    \
         const int key_ = (T_) * 10 + ((G_) ? 1 : 0);                                        \
         switch (key_) {                                                                     \
+        case 10: { CALL(1, 2, false); } break; case 11: { CALL(1, 2, true); } break;       \
         case 20: { CALL(2, 2, false); } break; case 21: { CALL(2, 2, true); } break;       \
         case 40: { CALL(4, 2, false); } break; case 41: { CALL(4, 2, true); } break;       \
         case 60: { CALL(6, 2, false); } break; case 61: { CALL(6, 2, true); } break;       \
@@ -778,11 +786,11 @@ static int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
         if (pl->kernel == DEFF_KERNEL_MATFREE_TB) {
             // sweeps per pass: 6 once the stack is big enough to fill the chip (measured at 4096^2:
             // T=4 919, T=6 1005, T=8 1046 G cells*iter/s; 16 x 1024^2: 879 / 966 / 932), else 4
-            int T = c->tb_T ? c->tb_T : (c->n >= ((size_t)1 << 22) ? 6 : 4);
-            T = T >= 8 ? 8 : T >= 6 ? 6 : T >= 4 ? 4 : 2;
+            int T = pl->T_override ? pl->T_override : (c->tb_T ? c->tb_T : (c->n >= ((size_t)1 << 22) ? 6 : 4));
+            T = T >= 8 ? 8 : T >= 6 ? 6 : T >= 4 ? 4 : T >= 2 ? 2 : 1;
             pl->T = T;
             pl->CPL = 2;
-            const int wout = 64 * pl->CPL - 2 * T;
+            const int wout = 64 * pl->CPL - 2 * ((T + 1) & ~1);
             pl->ntx = (c->nx + wout - 1) / wout;
             // Rows per chunk.  Workgroups are persistent and tiles cost the same, so the
             // pass takes rounds x (LY + 2T) row steps, where one round is as many block
@@ -797,16 +805,16 @@ static int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
                     // `resident` workgroups (4 waves each)
                     const int tgy_max = (int)(((long)k * resident * 4) / ((long)pl->ntx * c->nimg));
                     if (tgy_max < 1) continue;
-                    int ly = (c->ny + tgy_max - 1) / tgy_max;
+                    int ly = (c->own_h + tgy_max - 1) / tgy_max;
                     if (ly < 1) ly = 1;
                     const long cost = (long)k * (ly + 2 * T);
                     if (best_cost < 0 || cost < best_cost) { best_cost = cost; LY = ly; }
                 }
-                if (!LY) LY = c->ny;
+                if (!LY) LY = c->own_h;
             }
-            if (LY > c->ny) LY = c->ny;
+            if (LY > c->own_h) LY = c->own_h;
             pl->LY = LY;
-            pl->tcpi = (c->ny + LY - 1) / LY;
+            pl->tcpi = (c->own_h + LY - 1) / LY;
             pl->tgy = pl->tcpi * c->nimg;
             pl->tgx = (int)(((long)pl->ntx * pl->tgy + 3) / 4);       // workgroup tiles (4 wave tiles each)
             const unsigned total = (unsigned)pl->tgx;
@@ -905,8 +913,8 @@ static inline void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl)
     const uint8_t *mask = c->masked ? c->active : nullptr;
 #define LAUNCH_TB(T_, C_, G_)                                                                                  \
     hipLaunchKernelGGL((k_sweep_matfree_tb<T_, C_, G_>), dim3(pl.tblocks), dim3(256), 0, c->stream, c->lut_tb, \
-                       c->code, xin, xout, c->nx, c->ny, pl.tcpi, mask, pl.LY, pl.ntx, pl.tgx, pl.tgy, flip,  \
-                       c->tb_xmajor, pl.omw)
+                       c->code, xin, xout, c->nx, c->mesh_ny, c->ny, c->dom_lo, c->own_lo, c->own_h, pl.tcpi, \
+                       mask, pl.LY, pl.ntx, pl.tgx, pl.tgy, flip, c->tb_xmajor, pl.omw)
     TB_DISPATCH(pl.T, pl.CPL, pl.guard, LAUNCH_TB);
 #undef LAUNCH_TB
     c->cur ^= 1;
@@ -1092,5 +1100,355 @@ extern "C" int deff_last_launches(const deff_ctx *c, int64_t *launches, int *swe
             *sweeps_per_pass = T >= 8 ? 8 : T >= 6 ? 6 : T >= 4 ? 4 : 2;
         }
     }
+    return DEFF_OK;
+}
+
+// ====================================================================== row slabs ==
+//
+// One image split into N contiguous row slabs, one per GPU (BASELINE config #4).
+// The reference has nothing like it (cudaSetDevice(0), cuh:908).  Each slab is an ordinary
+// context whose arrays carry SLAB_HALO extra rows above and below its own rows; a temporally
+// blocked pass of T <= SLAB_HALO sweeps needs exactly T valid halo rows, so ONE exchange per
+// pass (not per sweep) refreshes them: every slab sends its first and last SLAB_HALO own rows
+// to its neighbours.  No arithmetic changes, so the assembled field is bit-identical to the
+// one-GPU field, and the wall fluxes are summed on the host in global row order, so Deff and the
+// stopping decision are too.
+//
+// This group drives all slabs from one host thread (one process, N devices; copies between
+// devices are hipMemcpyPeerAsync over xGMI, ordered by events) -- which is also what lets the
+// whole path be exercised with N slabs on a single GPU.  The process-per-GPU variant only swaps
+// the transport (RCCL send/recv of the same row blocks + an all-gather of the fluxes).
+
+static const int SLAB_HALO = 8;
+extern "C" int deff_slab_group_destroy(deff_slab_group *g);
+
+struct deff_slab_group {
+    int n = 0, nx = 0, NY = 0;
+    std::vector<deff_ctx *> ctx;
+    std::vector<int> g0, own;                 // first global row and row count of every slab
+    std::vector<hipEvent_t> done;             // "pass finished" per slab
+    std::vector<double> mfl, mfr;             // global wall fluxes of the last check
+};
+
+static int slab_create_ctx(int device, int nx, int NY, int g0, int own, deff_ctx **out)
+{
+    const int rows = own + 2 * SLAB_HALO;
+    TRY(deff_create_batch(device, nx, rows, 1, out));
+    deff_ctx *c = *out;
+    c->slab = true;
+    c->halo = SLAB_HALO;
+    c->dom_lo = SLAB_HALO - g0;               // array row of mesh row 0
+    c->mesh_ny = NY;
+    c->own_lo = SLAB_HALO;
+    c->own_h = own;
+    c->dy = 1.0 / NY;                         // the mesh is the whole image, cuh:1911
+    c->kernel = DEFF_KERNEL_MATFREE_TB;
+    return DEFF_OK;
+}
+
+extern "C" int deff_slab_group_create(int nslabs, const int *devices, int nx, int NY, deff_slab_group **out)
+{
+    if (!out || nslabs < 1) return fail(DEFF_EINVAL, "bad slab group arguments");
+    *out = nullptr;
+    if (nx < 2 || (nx & 1)) return fail(DEFF_EINVAL, "row-slab mode needs an even nx >= 2 (got %d)", nx);
+    if (NY / nslabs < SLAB_HALO) return fail(DEFF_EINVAL, "%d rows over %d slabs: fewer than %d rows per slab", NY, nslabs, SLAB_HALO);
+    deff_slab_group *g = new (std::nothrow) deff_slab_group();
+    if (!g) return fail(DEFF_ENOMEM, "host allocation failed");
+    g->n = nslabs; g->nx = nx; g->NY = NY;
+    g->mfl.assign(NY, 0.0); g->mfr.assign(NY, 0.0);
+    int rc = DEFF_OK;
+    for (int r = 0; r < nslabs && rc == DEFF_OK; ++r) {
+        const int a = (int)((long long)NY * r / nslabs), b = (int)((long long)NY * (r + 1) / nslabs);
+        deff_ctx *c = nullptr;
+        rc = slab_create_ctx(devices ? devices[r] : 0, nx, NY, a, b - a, &c);
+        if (rc != DEFF_OK) break;
+        g->ctx.push_back(c); g->g0.push_back(a); g->own.push_back(b - a);
+        hipEvent_t ev = nullptr;
+        if (hipSetDevice(c->device) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+            rc = fail(DEFF_EHIP, "event creation failed");
+        g->done.push_back(ev);
+    }
+    if (rc != DEFF_OK) { deff_slab_group_destroy(g); return rc; }
+    *out = g;
+    return DEFF_OK;
+}
+
+extern "C" int deff_slab_group_destroy(deff_slab_group *g)
+{
+    if (!g) return DEFF_OK;
+    for (size_t r = 0; r < g->ctx.size(); ++r) {
+        if (r < g->done.size() && g->done[r]) { (void)hipSetDevice(g->ctx[r]->device); (void)hipEventDestroy(g->done[r]); }
+        deff_destroy(g->ctx[r]);
+    }
+    delete g;
+    return DEFF_OK;
+}
+
+extern "C" int deff_slab_group_layout(const deff_slab_group *g, int *first_row, int *row_count)
+{
+    if (!g) return fail(DEFF_EINVAL, "group is NULL");
+    for (int r = 0; r < g->n; ++r) {
+        if (first_row) first_row[r] = g->g0[r];
+        if (row_count) row_count[r] = g->own[r];
+    }
+    return DEFF_OK;
+}
+
+// Array rows [lo, hi) of slab r as mesh rows, clipped to the mesh.
+static void slab_window(const deff_slab_group *g, int r, int *mesh_first, int *array_first, int *count)
+{
+    const deff_ctx *c = g->ctx[r];
+    int a = -c->dom_lo, b = a + c->rows;        // mesh rows covered by the array
+    int ar = 0;
+    if (a < 0) { ar = -a; a = 0; }
+    if (b > g->NY) b = g->NY;
+    *mesh_first = a; *array_first = ar; *count = b - a;
+}
+
+// pix: the whole image, NY x nx bytes (mesh amplification is not supported in slab mode)
+extern "C" int deff_slab_group_set_image(deff_slab_group *g, const uint8_t *pix)
+{
+    if (!g || !pix) return fail(DEFF_EINVAL, "NULL argument");
+    for (int r = 0; r < g->n; ++r) {
+        deff_ctx *c = g->ctx[r];
+        TRY(use_device(c));
+        TRY(image_shape(c, c->nx, c->ny, 1, 1));
+        HIP_TRY(hipMemsetAsync(c->pix, 0, c->n, c->stream));
+        int m0, a0, cnt;
+        slab_window(g, r, &m0, &a0, &cnt);
+        HIP_TRY(hipMemcpyAsync(c->pix + (size_t)a0 * c->nx, pix + (size_t)m0 * c->nx, (size_t)cnt * c->nx,
+                               hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->have_image = true; c->have_matfree = false;
+    }
+    return DEFF_OK;
+}
+
+extern "C" int deff_slab_group_synth_image(deff_slab_group *g, uint64_t seed, uint64_t img)
+{
+    if (!g) return fail(DEFF_EINVAL, "group is NULL");
+    for (int r = 0; r < g->n; ++r) {
+        deff_ctx *c = g->ctx[r];
+        TRY(use_device(c));
+        TRY(image_shape(c, c->nx, c->ny, 1, 1));
+        HIP_TRY(hipMemsetAsync(c->pix, 0, c->n, c->stream));
+        int m0, a0, cnt;
+        slab_window(g, r, &m0, &a0, &cnt);
+        // the generator's key is seed*K + img*NY*nx + global cell index: start it at mesh row m0
+        const uint64_t base_img_cells = img * (uint64_t)g->NY * (uint64_t)g->nx + (uint64_t)m0 * (uint64_t)g->nx;
+        hipLaunchKernelGGL(k_synth_mask_at, dim3(grid_for((size_t)cnt * c->nx)), dim3(256), 0, c->stream,
+                           c->pix + (size_t)a0 * c->nx, (size_t)cnt * c->nx, seed, base_img_cells);
+        HIP_TRY(hipGetLastError());
+        c->have_image = true; c->have_matfree = false;
+    }
+    return DEFF_OK;
+}
+
+extern "C" int deff_slab_group_assemble_2phase(deff_slab_group *g, double Ds, double Df, double CL, double CR)
+{
+    if (!g) return fail(DEFF_EINVAL, "group is NULL");
+    for (int r = 0; r < g->n; ++r) TRY(deff_assemble_2phase(g->ctx[r], Ds, Df, CL, CR));
+    return DEFF_OK;
+}
+
+extern "C" int deff_slab_group_init_linear(deff_slab_group *g, double CL, double CR)
+{
+    if (!g) return fail(DEFF_EINVAL, "group is NULL");
+    for (int r = 0; r < g->n; ++r) TRY(deff_init_linear(g->ctx[r], CL, CR));     // a function of the column only
+    return DEFF_OK;
+}
+
+extern "C" int deff_slab_group_set_field(deff_slab_group *g, const double *x)
+{
+    if (!g || !x) return fail(DEFF_EINVAL, "NULL argument");
+    for (int r = 0; r < g->n; ++r) {
+        deff_ctx *c = g->ctx[r];
+        TRY(use_device(c));
+        HIP_TRY(hipMemsetAsync(c->x[c->cur], 0, sizeof(double) * c->n, c->stream));
+        int m0, a0, cnt;
+        slab_window(g, r, &m0, &a0, &cnt);
+        HIP_TRY(hipMemcpyAsync(c->x[c->cur] + (size_t)a0 * c->nx, x + (size_t)m0 * c->nx,
+                               sizeof(double) * (size_t)cnt * c->nx, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->have_field = true;
+        reset_batch_state(c);
+    }
+    return DEFF_OK;
+}
+
+extern "C" int deff_slab_group_get_field(deff_slab_group *g, double *x)
+{
+    if (!g || !x) return fail(DEFF_EINVAL, "NULL argument");
+    for (int r = 0; r < g->n; ++r) {
+        deff_ctx *c = g->ctx[r];
+        TRY(use_device(c));
+        HIP_TRY(hipMemcpyAsync(x + (size_t)g->g0[r] * c->nx, c->x[c->cur] + (size_t)c->own_lo * c->nx,
+                               sizeof(double) * (size_t)g->own[r] * c->nx, hipMemcpyDeviceToHost, c->stream));
+    }
+    for (int r = 0; r < g->n; ++r) { TRY(use_device(g->ctx[r])); HIP_TRY(hipStreamSynchronize(g->ctx[r]->stream)); }
+    return DEFF_OK;
+}
+
+// After a pass: every slab's halo rows of the NEW field are stale; refill them from the
+// neighbours' own rows.  Copies run on the receiver's stream once the sender's pass is done.
+static int slab_exchange(deff_slab_group *g)
+{
+    const size_t blk = (size_t)SLAB_HALO * g->nx;                      // doubles per halo block
+    for (int r = 0; r < g->n; ++r) {
+        TRY(use_device(g->ctx[r]));
+        HIP_TRY(hipEventRecord(g->done[r], g->ctx[r]->stream));
+    }
+    for (int r = 0; r < g->n; ++r) {
+        deff_ctx *c = g->ctx[r];
+        TRY(use_device(c));
+        if (r > 0) {                                                   // top halo <- last own rows of slab r-1
+            deff_ctx *u = g->ctx[r - 1];
+            HIP_TRY(hipStreamWaitEvent(c->stream, g->done[r - 1], 0));
+            const double *src = u->x[u->cur] + (size_t)(u->own_lo + u->own_h - SLAB_HALO) * g->nx;
+            HIP_TRY(hipMemcpyPeerAsync(c->x[c->cur], c->device, src, u->device, sizeof(double) * blk, c->stream));
+        }
+        if (r + 1 < g->n) {                                            // bottom halo <- first own rows of slab r+1
+            deff_ctx *d = g->ctx[r + 1];
+            HIP_TRY(hipStreamWaitEvent(c->stream, g->done[r + 1], 0));
+            const double *src = d->x[d->cur] + (size_t)d->own_lo * g->nx;
+            HIP_TRY(hipMemcpyPeerAsync(c->x[c->cur] + (size_t)(c->own_lo + c->own_h) * g->nx, c->device, src,
+                                       d->device, sizeof(double) * blk, c->stream));
+        }
+    }
+    // a slab must not start its next pass (which overwrites x[cur^1] ... and whose result the
+    // neighbours will read) before the neighbours have taken their copies of this one
+    for (int r = 0; r < g->n; ++r) {
+        TRY(use_device(g->ctx[r]));
+        HIP_TRY(hipEventRecord(g->done[r], g->ctx[r]->stream));
+    }
+    for (int r = 0; r < g->n; ++r) {
+        TRY(use_device(g->ctx[r]));
+        if (r > 0) HIP_TRY(hipStreamWaitEvent(g->ctx[r]->stream, g->done[r - 1], 0));
+        if (r + 1 < g->n) HIP_TRY(hipStreamWaitEvent(g->ctx[r]->stream, g->done[r + 1], 0));
+    }
+    return DEFF_OK;
+}
+
+// n sweeps on every slab: blocked passes of T, remainder as T = 1 passes, one exchange per pass.
+static int slab_sweeps(deff_slab_group *g, std::vector<SweepPlan> &plT, std::vector<SweepPlan> &pl1, int64_t n)
+{
+    const int T = plT[0].T;
+    while (n > 0) {
+        const bool big = n >= T;
+        for (int r = 0; r < g->n; ++r) {
+            TRY(use_device(g->ctx[r]));
+            enqueue_tb_pass(g->ctx[r], big ? plT[r] : pl1[r]);
+            ++g->ctx[r]->last_launches;
+        }
+        HIP_TRY(hipGetLastError());
+        TRY(slab_exchange(g));
+        n -= big ? T : 1;
+    }
+    return DEFF_OK;
+}
+
+static int slab_plans(deff_slab_group *g, double omega, std::vector<SweepPlan> &plT, std::vector<SweepPlan> &pl1)
+{
+    plT.assign(g->n, SweepPlan()); pl1.assign(g->n, SweepPlan());
+    for (int r = 0; r < g->n; ++r) {
+        deff_ctx *c = g->ctx[r];
+        TRY(use_device(c));
+        if (c->tb_T > SLAB_HALO) return fail(DEFF_EINVAL, "tb_T exceeds the slab halo depth %d", SLAB_HALO);
+        TRY(plan_sweeps(c, omega, &plT[r]));
+        if (plT[r].kernel != DEFF_KERNEL_MATFREE_TB) return fail(DEFF_ESTATE, "row-slab mode needs the temporally blocked kernel");
+        pl1[r].T_override = 1;
+        TRY(plan_sweeps(c, omega, &pl1[r]));
+        c->last_launches = 0;
+    }
+    return DEFF_OK;
+}
+
+extern "C" int deff_slab_group_sweeps(deff_slab_group *g, int64_t n, double omega, float *ms)
+{
+    if (!g || n < 0) return fail(DEFF_EINVAL, "bad arguments");
+    std::vector<SweepPlan> plT, pl1;
+    TRY(slab_plans(g, omega, plT, pl1));
+    deff_ctx *c0 = g->ctx[0];
+    TRY(use_device(c0));
+    HIP_TRY(hipEventRecord(c0->ev0, c0->stream));
+    TRY(slab_sweeps(g, plT, pl1, n));
+    for (int r = 0; r < g->n; ++r) { TRY(use_device(g->ctx[r])); HIP_TRY(hipStreamSynchronize(g->ctx[r]->stream)); }
+    TRY(use_device(c0));
+    HIP_TRY(hipEventRecord(c0->ev1, c0->stream));
+    HIP_TRY(hipEventSynchronize(c0->ev1));
+    if (ms) HIP_TRY(hipEventElapsedTime(ms, c0->ev0, c0->ev1));
+    return DEFF_OK;
+}
+
+// Wall fluxes of every slab's own rows -> the group's global arrays -> Deff (cuh:1252-1263),
+// summed in global row order exactly like the one-GPU path.
+static int slab_flux(deff_slab_group *g, double *deff_raw)
+{
+    for (int r = 0; r < g->n; ++r) { TRY(use_device(g->ctx[r])); TRY(flux_rows(g->ctx[r])); }
+    for (int r = 0; r < g->n; ++r) {
+        const deff_ctx *c = g->ctx[r];
+        memcpy(&g->mfl[g->g0[r]], c->mf_host + c->own_lo, sizeof(double) * g->own[r]);
+        memcpy(&g->mfr[g->g0[r]], c->mf_host + c->rows + c->own_lo, sizeof(double) * g->own[r]);
+    }
+    double Q1 = 0, Q2 = 0;
+    for (int j = 0; j < g->NY; ++j) { Q1 += g->mfl[j]; Q2 += g->mfr[j]; }
+    const deff_ctx *c = g->ctx[0];
+    const double qAvg = (Q1 + Q2) / (2.0 * g->NY);
+    *deff_raw = qAvg / ((c->CR - c->CL));
+    return DEFF_OK;
+}
+
+extern "C" int deff_slab_group_flux(deff_slab_group *g, double *deff_raw, double *MFL, double *MFR)
+{
+    if (!g || !deff_raw) return fail(DEFF_EINVAL, "NULL argument");
+    TRY(slab_flux(g, deff_raw));
+    if (MFL) memcpy(MFL, g->mfl.data(), sizeof(double) * g->NY);
+    if (MFR) memcpy(MFR, g->mfr.data(), sizeof(double) * g->NY);
+    return DEFF_OK;
+}
+
+// JacobiGPU's loop (cuh:1232-1290) over the slabs; same stopping rule as deff_solve.
+extern "C" int deff_slab_group_solve(deff_slab_group *g, double omega, double tol, int64_t max_iter,
+                                     int64_t check_every, deff_result *out, double *MFL, double *MFR)
+{
+    if (!g || !out) return fail(DEFF_EINVAL, "NULL argument");
+    if (check_every < 1) return fail(DEFF_EINVAL, "check_every must be >= 1");
+    std::vector<SweepPlan> plT, pl1;
+    TRY(slab_plans(g, omega, plT, pl1));
+    deff_ctx *c0 = g->ctx[0];
+    int64_t iter = 0, checks = 0;
+    double deffNew = 1, deffOld = 5, change = 100.0, conv = 0;      // cuh:1171-1173
+    TRY(use_device(c0));
+    HIP_TRY(hipEventRecord(c0->ev0, c0->stream));
+    while (iter < max_iter && tol < fabs(change)) {                  // cuh:1232
+        const int64_t next_check = ((iter + check_every - 1) / check_every) * check_every;
+        const bool do_check = next_check < max_iter;
+        const int64_t batch = do_check ? next_check - iter + 1 : max_iter - iter;
+        TRY(slab_sweeps(g, plT, pl1, batch));
+        iter += batch;
+        if (do_check) {
+            TRY(slab_flux(g, &deffNew));
+            change = (deffOld - deffNew) / (deffOld);                // cuh:1265
+            deffOld = deffNew;
+            conv = change;
+            ++checks;
+        }
+    }
+    for (int r = 0; r < g->n; ++r) { TRY(use_device(g->ctx[r])); HIP_TRY(hipStreamSynchronize(g->ctx[r]->stream)); }
+    TRY(use_device(c0));
+    HIP_TRY(hipEventRecord(c0->ev1, c0->stream));
+    HIP_TRY(hipEventSynchronize(c0->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c0->ev0, c0->ev1));
+    out->iters = iter; out->checks = checks; out->deff_raw = deffNew; out->conv = conv; out->loop_ms = ms;
+    if (MFL) memcpy(MFL, g->mfl.data(), sizeof(double) * g->NY);
+    if (MFR) memcpy(MFR, g->mfr.data(), sizeof(double) * g->NY);
+    return DEFF_OK;
+}
+
+extern "C" int deff_slab_group_set_tuning(deff_slab_group *g, const char *key, int value)
+{
+    if (!g) return fail(DEFF_EINVAL, "group is NULL");
+    for (int r = 0; r < g->n; ++r) TRY(deff_set_tuning(g->ctx[r], key, value));
     return DEFF_OK;
 }

@@ -36,6 +36,16 @@ __global__ void k_synth_mask(uint8_t *__restrict__ pix, int nx, int ny, uint64_t
         pix[p] = (splitmix64(base + p) >> 63) ? 255 : 0;
 }
 
+// Same generator for `count` consecutive cells starting at global cell index `first` of the
+// image sequence (row slabs generate only their own window of the image).
+__global__ void k_synth_mask_at(uint8_t *__restrict__ pix, size_t count, uint64_t seed, uint64_t first)
+{
+    const uint64_t base = seed * 0x100000001B3ull + first;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < count;
+         p += (size_t)gridDim.x * blockDim.x)
+        pix[p] = (splitmix64(base + p) >> 63) ? 255 : 0;
+}
+
 // Pixel of mesh cell (i, j) under nearest-neighbour amplification, cuh:1992-1994.
 // (i is the stacked row: image i / ny, row i % ny of that image; H = ny / ampY.)
 __device__ __forceinline__ uint8_t cell_pixel(const uint8_t *pix, int W, int ampX, int ampY, int ny,
@@ -99,15 +109,20 @@ __global__ void k_wall_D_from_D(const double *__restrict__ D, int nx, int rows,
 // neighbour phases.  Neighbours outside the mesh read the clamped cell; their bits are
 // never used because the lookup tables are selected by position class.
 __global__ void k_phase_codes(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
-                              int nx, int ny, int rows, uint8_t *__restrict__ code)
+                              int nx, int ny, int rows, int dom_lo, int mesh_ny,
+                              uint8_t *__restrict__ code)
 {
+    // dom_lo / mesh_ny: array row li of an image is mesh row li - dom_lo of a mesh_ny-row mesh
+    // (dom_lo = 0, mesh_ny = ny except for a row slab, whose array is a window with halo rows)
     const size_t n = (size_t)nx * rows;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
          p += (size_t)gridDim.x * blockDim.x) {
         int i = (int)(p / nx), j = (int)(p % nx);
-        const int li = i % ny;                       // row inside its image
+        const int li = i % ny;                       // row inside its image's array
+        const int gi = li - dom_lo;                  // mesh row
         int jw = j > 0 ? j - 1 : j, je = j < nx - 1 ? j + 1 : j;
-        int is = li < ny - 1 ? i + 1 : i, in = li > 0 ? i - 1 : i;
+        int is = (gi < mesh_ny - 1 && li < ny - 1) ? i + 1 : i;
+        int in = (gi > 0 && li > 0) ? i - 1 : i;
         unsigned c = (cell_pixel(pix, W, ampX, ampY, ny, i, j) >= 150) ? 1u : 0u;
         c |= (cell_pixel(pix, W, ampX, ampY, ny, i, jw) >= 150) ? 2u : 0u;
         c |= (cell_pixel(pix, W, ampX, ampY, ny, i, je) >= 150) ? 4u : 0u;

@@ -100,8 +100,11 @@ __device__ __forceinline__ int tb_ycls(int r, int ny)
 }
 
 // One strip x chunk: the whole row pipeline of a wave (2 cells per lane, 128 columns).
-// The chunk is rows [ry0, ry0+LY) of the image occupying stacked rows [row_lo, row_lo+ny);
-// rows outside that image are "outside the mesh" even if another image of the batch lives there.
+// Geometry (array rows): the mesh of this image is rows [row_lo, row_lo+ny) -- rows outside it
+// are "outside the mesh" even if another image of a batch lives there, and row_lo is negative
+// for a row slab whose array is a window into a taller image; the chunk computes rows
+// [ry0, min(ry0+LY, own_hi)), own_hi being the end of the rows this launch owns (the image in a
+// batch, the slab's own rows -- without its halo -- in a multi-GPU run).
 // (Variants measured and dropped: 4 cells per lane -- 244 VGPRs, 2 waves/SIMD, 20 % slower;
 // a skewed pipeline whose T updates per step are independent -- 198 VGPRs, no faster.  The
 // code is deliberately written with double2 values and named slots: an array-of-scalars
@@ -109,14 +112,17 @@ __device__ __forceinline__ int tb_ycls(int r, int ny)
 template <int T, bool GUARD, bool WALL>
 __device__ __forceinline__ void tb_strip(const double *lut, const uint8_t *__restrict__ code,
                                          const double *__restrict__ x, double *__restrict__ xnew, int nx,
-                                         int ny, int row_lo, int tx, int ry0, int LY, int lane, double omw)
+                                         int ny, int row_lo, int own_hi, int tx, int ry0, int LY, int lane,
+                                         double omw)
 {
-    constexpr int WOUT = TB_COLS - 2 * T;
+    // column halo rounded up to even so that odd T keeps the 16-B alignment of a lane's pair
+    constexpr int HW = (T + 1) & ~1;
+    constexpr int WOUT = TB_COLS - 2 * HW;
     const int cx0 = tx * WOUT;                     // first output column of the strip
-    const int col = cx0 - T + 2 * lane;            // this lane's first column (even)
+    const int col = cx0 - HW + 2 * lane;           // this lane's first column (even)
     const bool in_x = (col >= 0) && (col < nx);    // nx even => col+1 < nx too
     const int row_hi = row_lo + ny;
-    const int ry1 = min(ry0 + LY, row_hi);
+    const int ry1 = min(ry0 + LY, own_hi);
     const int r_begin = ry0 - T, r_end = ry1 + T;  // input rows [r_begin, r_end)
     const bool st_x = in_x && (col >= cx0) && (col < cx0 + WOUT);
     // byte offsets of the two cells' x position class groups (3 = outside the mesh)
@@ -197,13 +203,19 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint8_t *__res
 // strip-major (wt = tx*gy + ty) and dealt 4 per workgroup, so the 4 waves of a workgroup
 // normally hold 4 vertically adjacent chunks of one strip (shared halo rows stay in L1/L2)
 // and no wave idles because the strip count is not a multiple of 4.  `gx` = number of
-// workgroup tiles = ceil(ntx*gy / 4); gy = nimg * cpi chunks.  nx must be even, T even.
+// workgroup tiles = ceil(ntx*gy / 4); gy = nimg * cpi chunks.  nx must be even.
+// Image k of a stack: mesh rows [dom_lo + k*img_stride, ... + ny), owned rows
+// [own_lo + k*img_stride, ... + own_h).  Batch: dom_lo = own_lo = 0, own_h = img_stride = ny.
+// Row slab (one image): dom_lo = -(first array row's global index), ny = global height,
+// own_lo = halo depth, own_h = rows owned by this rank.
 template <int T, int CPL, bool GUARD>
 __global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restrict__ lut_g,
                                                           const uint8_t *__restrict__ code,
                                                           const double *__restrict__ x,
                                                           double *__restrict__ xnew, int nx, int ny,
-                                                          int cpi, const uint8_t *__restrict__ active,
+                                                          int img_stride, int dom_lo, int own_lo,
+                                                          int own_h, int cpi,
+                                                          const uint8_t *__restrict__ active,
                                                           int LY, int ntx, int nbt, int gy, int flip,
                                                           int xmajor, double omw)
 {
@@ -233,13 +245,14 @@ __global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restri
         const int bty = xmajor ? (int)(wt / (unsigned)ntx) : (int)(wt % (unsigned)gy);
         const int img = bty / cpi;                     // cpi chunks per image, gy = nimg * cpi
         if (active && !active[img]) continue;          // frozen image of a batch
-        const int row_lo = img * ny;
-        const int ry0 = row_lo + (bty - img * cpi) * LY;
+        const int row_lo = dom_lo + img * img_stride;
+        const int own0 = own_lo + img * img_stride;
+        const int ry0 = own0 + (bty - img * cpi) * LY;
 
         if (tx == 0 || tx == ntx - 1)
-            tb_strip<T, GUARD, true>(lut, code, x, xnew, nx, ny, row_lo, tx, ry0, LY, lane, omw);
+            tb_strip<T, GUARD, true>(lut, code, x, xnew, nx, ny, row_lo, own0 + own_h, tx, ry0, LY, lane, omw);
         else
-            tb_strip<T, GUARD, false>(lut, code, x, xnew, nx, ny, row_lo, tx, ry0, LY, lane, omw);
+            tb_strip<T, GUARD, false>(lut, code, x, xnew, nx, ny, row_lo, own0 + own_h, tx, ry0, LY, lane, omw);
     }
 }
 

@@ -189,6 +189,87 @@ class Solver:
         check(self._L.deff_synchronize(self._ctx))
 
 
+class SlabGroup:
+    """One image split into row slabs over `devices` (one slab per entry; entries may repeat,
+    which is how the multi-GPU path is exercised on a single GPU).  Same call sequence as Solver."""
+
+    def __init__(self, nx, NY, devices):
+        self._L = _capi.load()
+        self._g = C.c_void_p()
+        self.nx, self.ny, self.nslabs = int(nx), int(NY), len(devices)
+        dev = (C.c_int * len(devices))(*devices)
+        check(self._L.deff_slab_group_create(len(devices), dev, self.nx, self.ny, C.byref(self._g)))
+
+    def close(self):
+        if self._g:
+            self._L.deff_slab_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def layout(self):
+        a = (C.c_int * self.nslabs)()
+        b = (C.c_int * self.nslabs)()
+        check(self._L.deff_slab_group_layout(self._g, a, b))
+        return list(a), list(b)
+
+    def set_tuning(self, key, value):
+        check(self._L.deff_slab_group_set_tuning(self._g, key.encode(), int(value)))
+
+    def set_image(self, pix):
+        pix = np.ascontiguousarray(pix, dtype=np.uint8)
+        assert pix.shape == (self.ny, self.nx)
+        check(self._L.deff_slab_group_set_image(self._g, pix))
+
+    def synth_image(self, seed=12345, img=0):
+        check(self._L.deff_slab_group_synth_image(self._g, seed, img))
+
+    def assemble_2phase(self, Ds, Df, CL, CR):
+        check(self._L.deff_slab_group_assemble_2phase(self._g, Ds, Df, CL, CR))
+
+    def init_linear(self, CL, CR):
+        check(self._L.deff_slab_group_init_linear(self._g, CL, CR))
+
+    def set_field(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.size == self.nx * self.ny
+        check(self._L.deff_slab_group_set_field(self._g, x))
+
+    def get_field(self):
+        x = np.empty((self.ny, self.nx), dtype=np.float64)
+        check(self._L.deff_slab_group_get_field(self._g, x))
+        return x
+
+    def sweeps(self, n, omega=OMEGA_REFERENCE):
+        ms = C.c_float()
+        check(self._L.deff_slab_group_sweeps(self._g, int(n), omega, C.byref(ms)))
+        return ms.value
+
+    def flux(self):
+        d = C.c_double()
+        MFL = np.zeros(self.ny)
+        MFR = np.zeros(self.ny)
+        check(self._L.deff_slab_group_flux(self._g, C.byref(d), MFL.ctypes.data_as(C.c_void_p),
+                                           MFR.ctypes.data_as(C.c_void_p)))
+        return d.value, MFL, MFR
+
+    def solve(self, tol, max_iter, omega=OMEGA_REFERENCE, check_every=10000):
+        res = Result()
+        MFL = np.zeros(self.ny)
+        MFR = np.zeros(self.ny)
+        check(self._L.deff_slab_group_solve(self._g, omega, tol, int(max_iter), int(check_every), C.byref(res),
+                                            MFL.ctypes.data_as(C.c_void_p), MFR.ctypes.data_as(C.c_void_p)))
+        out = SolveResult()
+        out.iters, out.checks = res.iters, res.checks
+        out.deff_raw, out.conv, out.loop_ms = res.deff_raw, res.conv, res.loop_ms
+        out.MFL, out.MFR = MFL, MFR
+        return out
+
+
 def flood_fill(grid):
     """FloodFill (Deff2D.cuh:557-713): grid (ny, nx) with 1 = solid -> (grid with unreachable
     pore cells = 2, PathFlag).  Host function of the library; needs no GPU."""
@@ -199,4 +280,4 @@ def flood_fill(grid):
     return g, bool(flag.value)
 
 
-__all__ = ["Solver", "flood_fill", "SolveResult", "DeffError", "OMEGA_REFERENCE"]
+__all__ = ["Solver", "SlabGroup", "flood_fill", "SolveResult", "DeffError", "OMEGA_REFERENCE"]

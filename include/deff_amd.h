@@ -135,6 +135,27 @@ int deff_flux(deff_ctx *ctx, double *deff_raw /* [nimg] */, double *MFL, double 
  * temporally blocked launch performs (1 for the single-sweep kernels) */
 int deff_last_launches(const deff_ctx *ctx, int64_t *launches, int *sweeps_per_pass);
 
+/* ---- row slabs: ONE image split over several GPUs (BASELINE config #4; nothing like it in the
+ * reference, which is pinned to device 0, cuh:908).  Slab r owns a contiguous block of rows and
+ * keeps 8 halo rows on each side; one neighbour exchange per temporally blocked pass keeps them
+ * valid; results are bit-identical to the one-GPU path.  This group form drives all slabs from
+ * one process (devices[r] may repeat: N slabs on one GPU is how the path is tested on one GPU). */
+typedef struct deff_slab_group deff_slab_group;
+int deff_slab_group_create(int nslabs, const int *devices, int nx, int NY, deff_slab_group **out);
+int deff_slab_group_destroy(deff_slab_group *g);
+int deff_slab_group_layout(const deff_slab_group *g, int *first_row, int *row_count);
+int deff_slab_group_set_tuning(deff_slab_group *g, const char *key, int value);
+int deff_slab_group_set_image(deff_slab_group *g, const uint8_t *pix /* NY*nx */);
+int deff_slab_group_synth_image(deff_slab_group *g, uint64_t seed, uint64_t img);
+int deff_slab_group_assemble_2phase(deff_slab_group *g, double Ds, double Df, double CL, double CR);
+int deff_slab_group_init_linear(deff_slab_group *g, double CL, double CR);
+int deff_slab_group_set_field(deff_slab_group *g, const double *x /* NY*nx */);
+int deff_slab_group_get_field(deff_slab_group *g, double *x /* NY*nx */);
+int deff_slab_group_sweeps(deff_slab_group *g, int64_t n, double omega, float *ms);
+int deff_slab_group_flux(deff_slab_group *g, double *deff_raw, double *MFL, double *MFR);
+int deff_slab_group_solve(deff_slab_group *g, double omega, double tol, int64_t max_iter,
+                          int64_t check_every, deff_result *out, double *MFL, double *MFR);
+
 /* raw device pointers for zero-copy interop (torch tensors, RCCL): current field,
  * and the byte pitch between rows (nx*8: rows are dense) */
 int deff_device_field(deff_ctx *ctx, void **d_x, size_t *row_pitch_bytes);

@@ -309,6 +309,73 @@ def test_batch_synthetic_first_check_at_1024(pkg, oracle, recorded):
     assert res[2].deff_raw == d
 
 
+# ----------------------------------------------------------------- row slabs
+
+@pytest.mark.parametrize("nslabs", [2, 3, 4])
+@pytest.mark.parametrize("T", [0, 2, 8])
+def test_row_slabs_equal_single_domain(pkg, oracle, nslabs, T):
+    """One image over several slabs with halo exchange once per blocked pass (all slabs on
+    device 0 here): the assembled field is bit-identical to the oracle / one-context field, the
+    fluxes and Deff too (they are summed in global row order)."""
+    nx, NY = 384, 203
+    rng = np.random.default_rng(nslabs * 10 + T)
+    pix = rand_mask(rng, nx, NY, 0.55)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-3)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    x0 = rng.random((NY, nx))
+    want = oracle.sweeps(A, b, x0, 29)
+    with pkg.SlabGroup(nx, NY, [0] * nslabs) as g:
+        first, count = g.layout()
+        assert first[0] == 0 and sum(count) == NY and all(c >= 8 for c in count)
+        g.set_tuning("tb_T", T)
+        g.set_image(pix)
+        g.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        g.set_field(x0)
+        g.sweeps(29)                       # passes of T plus single-sweep passes, exchange after each
+        assert_field(g.get_field(), want)
+        d, MFL, MFR = g.flux()
+        dor, MFLo, MFRo = oracle.flux_deff(want, D, 0.0, 1.0)
+        assert d == dor and np.array_equal(MFL, MFLo) and np.array_equal(MFR, MFRo)
+
+
+def test_row_slabs_solve_matches_single_context(pkg, oracle):
+    nx, NY = 256, 160
+    rng = np.random.default_rng(77)
+    pix = rand_mask(rng, nx, NY, 0.6)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-2)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    it, deff, conv, x, MFL, MFR = oracle.jacobi(A, b, oracle.linear_guess(nx, NY, 0.0, 1.0), D, 0.0, 1.0, 1e-3,
+                                                3000, check_every=100)
+    with pkg.SlabGroup(nx, NY, [0, 0, 0]) as g:
+        g.set_image(pix)
+        g.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+        g.init_linear(0.0, 1.0)
+        r = g.solve(1e-3, 3000, check_every=100)
+        assert (r.iters, r.deff_raw, r.conv) == (it, deff, conv)
+        assert_field(g.get_field(), x)
+        assert np.array_equal(r.MFL, MFL) and np.array_equal(r.MFR, MFR)
+
+
+def test_row_slabs_4096_equals_one_gpu(pkg, recorded):
+    """BASELINE config #4's check at a size that fits one GPU: 4 slabs of a 4096^2 synthetic image
+    against the one-context run, bit for bit, plus the reference's recorded first-check Deff."""
+    n = 4096
+    with pkg.Solver(n, n) as s:
+        s.synth_image(12345, 0)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(37)
+        ref = s.get_field()
+    with pkg.SlabGroup(n, n, [0, 0, 0, 0]) as g:
+        g.synth_image(12345, 0)
+        g.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        g.init_linear(0.0, 1.0)
+        r = g.solve(1e-6, 1)
+        assert r.deff_raw == recorded["synthetic_first_check_deff"]["4096"]
+        g.sweeps(36)
+        assert np.array_equal(g.get_field(), ref)
+
+
 def test_host_assembled_system_drop_in(pkg, oracle):
     """The reference's own arrays (A AoS, b, D) go in unchanged: set_system + solve."""
     rng = np.random.default_rng(11)
