@@ -51,6 +51,48 @@ def cpu_baseline(n, seconds_target=12.0):
                       f"host has {os.cpu_count()} logical CPUs"}
 
 
+def bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier):
+    """One --size x --size image split into `world` row slabs (RCCL halo exchange per blocked pass)."""
+    n, S = args.size, args.sweeps_per_step
+    uid = [pkg.rccl_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(uid, src=0)
+    s = pkg.SlabRank(n, n, rank, world, uid[0], device=local_rank)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        s.set_tuning(k, int(v))
+    s.synth_image(12345, 0)
+    s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+    s.init_linear(0.0, 1.0)
+    for _ in range(args.warmup):
+        s.sweeps(S, args.omega)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s.sweeps(S, args.omega)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        cells = float(n) * n
+        print(json.dumps({
+            "metric": f"Mcells*iter/s (Jacobi sweep) at {n}^2, row slabs", "value": cells * S * args.steps / elapsed / 1e6,
+            "unit": "Mcells*iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"ONE {n}x{n} synthetic two-phase image split into {world} row slabs, 8-row halos, "
+                                   f"RCCL send/recv once per temporally blocked pass; step = {S} sweeps",
+                       "kernel": "matfree_tb", "sweeps_per_step": S}}), flush=True)
+    s.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,6 +106,10 @@ def main():
     ap.add_argument("--explicit-sweeps", type=int, default=300,
                     help="sweeps of the secondary explicit-coefficient measurement (0 = skip)")
     ap.add_argument("--tune", action="append", default=[], help="key=value tuning knob (repeatable)")
+    ap.add_argument("--mode", default="images", choices=["images", "slab"],
+                    help="images: one image per GPU, no collective (default, weak scaling); slab: ONE image of "
+                         "--size rows split into row slabs over the GPUs with RCCL halo exchange (config #4, strong)")
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU swept together (dataset-generation mode)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,18 +135,20 @@ def main():
             dist.barrier(device_ids=[local_rank])
 
     n, S = args.size, args.sweeps_per_step
-    s = pkg.Solver(n, n, device=local_rank, kernel=args.kernel)
+    if args.mode == "slab":
+        return bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier)
+    s = pkg.Solver(n, n, device=local_rank, kernel=args.kernel, nimg=args.batch)
     for kv in args.tune:
         k, v = kv.split("=")
         s.set_tuning(k, int(v))
-    s.synth_image(12345, rank)                  # image index = rank: independent images, no comm
+    s.synth_image(12345, rank * args.batch)     # image index = rank (x batch): independent images, no comm
     s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
     s.init_linear(0.0, 1.0)
 
     def step():
         ms = s.sweeps(S, args.omega)
         deff, _, _ = s.flux()
-        return ms, deff
+        return ms, (deff if args.batch == 1 else float(deff[0]))
 
     for _ in range(args.warmup):
         step()
@@ -134,7 +182,7 @@ def main():
         s.set_kernel(args.kernel)
 
     if rank == 0:
-        cells = float(n) * n
+        cells = float(n) * n * args.batch
         total_launches = args.steps * launches
         launch_s = kernel_ms * 1e-3 / total_launches      # avg duration of one sweep-kernel launch (HIP events)
         alg_bytes = BYTES_PER_CELL_SWEEP * cells * sweeps_per_launch
@@ -163,7 +211,7 @@ def main():
             "config": {
                 "workload": f"{n}x{n} synthetic two-phase image (splitmix64 seed 12345, porosity 0.5), Ds=1e-3 Df=1 "
                             f"CL=0 CR=1, omega={args.omega:.6g}; step = {S} sweeps + 1 Deff evaluation; "
-                            f"one image per GPU (image index = rank)",
+                            f"{args.batch} image(s) per GPU (image index = rank), no inter-GPU communication",
                 "kernel": kernel_used,
                 "sweeps_per_step": S,
                 "sweeps_per_launch": sweeps_per_launch,

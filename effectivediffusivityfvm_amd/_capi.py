@@ -25,6 +25,9 @@ SYMBOLS = [
     "deff_slab_group_set_image", "deff_slab_group_synth_image", "deff_slab_group_assemble_2phase",
     "deff_slab_group_init_linear", "deff_slab_group_set_field", "deff_slab_group_get_field",
     "deff_slab_group_sweeps", "deff_slab_group_flux", "deff_slab_group_solve",
+    "deff_rccl_unique_id", "deff_slab_rank_create", "deff_slab_rank_destroy", "deff_slab_rank_layout",
+    "deff_slab_rank_window", "deff_slab_rank_context", "deff_slab_rank_set_image_window",
+    "deff_slab_rank_synth_image", "deff_slab_rank_get_field", "deff_slab_rank_sweeps", "deff_slab_rank_solve",
     "deff_flux", "deff_set_progress", "deff_last_launches", "deff_device_field", "deff_synchronize",
 ]
 
@@ -108,6 +111,18 @@ def load():
     L.deff_slab_group_flux.argtypes = [ctx, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
     L.deff_slab_group_solve.argtypes = [ctx, C.c_double, C.c_double, C.c_int64, C.c_int64, C.POINTER(Result),
                                         C.c_void_p, C.c_void_p]
+    L.deff_rccl_unique_id.argtypes = [C.c_char_p]
+    L.deff_slab_rank_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(ctx)]
+    L.deff_slab_rank_destroy.argtypes = [ctx]
+    L.deff_slab_rank_layout.argtypes = [ctx, ip, ip]
+    L.deff_slab_rank_window.argtypes = [ctx, ip, ip]
+    L.deff_slab_rank_context.argtypes = [ctx, C.POINTER(ctx)]
+    L.deff_slab_rank_set_image_window.argtypes = [ctx, _u8p]
+    L.deff_slab_rank_synth_image.argtypes = [ctx, C.c_uint64, C.c_uint64]
+    L.deff_slab_rank_get_field.argtypes = [ctx, _dp]
+    L.deff_slab_rank_sweeps.argtypes = [ctx, C.c_int64, C.c_double, C.POINTER(C.c_float)]
+    L.deff_slab_rank_solve.argtypes = [ctx, C.c_double, C.c_double, C.c_int64, C.c_int64, C.POINTER(Result),
+                                       C.c_void_p, C.c_void_p]
     L.deff_device_field.argtypes = [ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.deff_synchronize.argtypes = [ctx]
     for name in SYMBOLS:

@@ -9,6 +9,7 @@
 // ping-pong (no per-sweep sync or D2D copy, unlike cuh:1239/cuh:1281); a
 // convergence check moves 16*ny bytes, not the field (cuh:1245).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -1450,5 +1451,293 @@ extern "C" int deff_slab_group_set_tuning(deff_slab_group *g, const char *key, i
 {
     if (!g) return fail(DEFF_EINVAL, "group is NULL");
     for (int r = 0; r < g->n; ++r) TRY(deff_set_tuning(g->ctx[r], key, value));
+    return DEFF_OK;
+}
+
+// ------------------------------------------------- row slabs, one process per GPU (RCCL) --
+//
+// Same slab contexts and the same loop as the group above; only the transport differs: the halo
+// blocks travel by grouped ncclSend/ncclRecv between neighbouring ranks on the context's stream
+// (point-to-point over one xGMI link per neighbour pair; 8 rows x nx doubles, 1 MiB at nx =
+// 16384, once per blocked pass), and the per-row wall fluxes are all-gathered so that every rank
+// sums them in global row order and takes the same stop/continue decision.
+
+struct deff_slab_rank {
+    deff_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1, nx = 0, NY = 0, maxown = 0;
+    std::vector<int> g0, own;
+    double *d_pack = nullptr, *d_all = nullptr;      // [2*maxown], [nranks*2*maxown]
+    std::vector<double> h_all, mfl, mfr;
+};
+
+#define NCCL_TRY(expr)                                                                          \
+    do {                                                                                        \
+        ncclResult_t r_ = (expr);                                                               \
+        if (r_ != ncclSuccess)                                                                  \
+            return fail(DEFF_ECOMM, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" int deff_rccl_unique_id(char *id128)
+{
+    if (!id128) return fail(DEFF_EINVAL, "id buffer is NULL");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    memcpy(id128, &id, sizeof id);
+    return DEFF_OK;
+}
+
+extern "C" int deff_slab_rank_destroy(deff_slab_rank *s)
+{
+    if (!s) return DEFF_OK;
+    if (s->ctx) (void)hipSetDevice(s->ctx->device);
+    if (s->d_pack) (void)hipFree(s->d_pack);
+    if (s->d_all) (void)hipFree(s->d_all);
+    if (s->comm) (void)ncclCommDestroy(s->comm);
+    deff_destroy(s->ctx);
+    delete s;
+    return DEFF_OK;
+}
+
+extern "C" int deff_slab_rank_create(int device, int nx, int NY, int rank, int nranks, const char *id128,
+                                     deff_slab_rank **out)
+{
+    if (!out || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(DEFF_EINVAL, "bad slab rank arguments");
+    *out = nullptr;
+    if (nx < 2 || (nx & 1)) return fail(DEFF_EINVAL, "row-slab mode needs an even nx >= 2 (got %d)", nx);
+    if (NY / nranks < SLAB_HALO) return fail(DEFF_EINVAL, "%d rows over %d ranks: fewer than %d rows per slab", NY, nranks, SLAB_HALO);
+    deff_slab_rank *s = new (std::nothrow) deff_slab_rank();
+    if (!s) return fail(DEFF_ENOMEM, "host allocation failed");
+    s->rank = rank; s->nranks = nranks; s->nx = nx; s->NY = NY;
+    for (int r = 0; r < nranks; ++r) {
+        const int a = (int)((long long)NY * r / nranks), b = (int)((long long)NY * (r + 1) / nranks);
+        s->g0.push_back(a); s->own.push_back(b - a);
+        if (b - a > s->maxown) s->maxown = b - a;
+    }
+    s->mfl.assign(NY, 0.0); s->mfr.assign(NY, 0.0);
+    s->h_all.assign((size_t)nranks * 2 * s->maxown, 0.0);
+    int rc = slab_create_ctx(device, nx, NY, s->g0[rank], s->own[rank], &s->ctx);
+    if (rc == DEFF_OK) {
+        ncclUniqueId id;
+        memcpy(&id, id128, sizeof id);
+        hipError_t he;
+        ncclResult_t nr;
+        if ((he = hipSetDevice(device)) != hipSuccess) rc = fail(DEFF_EHIP, "hipSetDevice: %s", hipGetErrorString(he));
+        else if ((nr = ncclCommInitRank(&s->comm, nranks, id, rank)) != ncclSuccess)
+            rc = fail(DEFF_ECOMM, "ncclCommInitRank: %s", ncclGetErrorString(nr));
+        else if ((he = hipMalloc((void **)&s->d_pack, sizeof(double) * 2 * s->maxown)) != hipSuccess ||
+                 (he = hipMalloc((void **)&s->d_all, sizeof(double) * 2 * s->maxown * nranks)) != hipSuccess)
+            rc = fail(DEFF_ENOMEM, "hipMalloc: %s", hipGetErrorString(he));
+        else if ((he = hipMemset(s->d_pack, 0, sizeof(double) * 2 * s->maxown)) != hipSuccess)
+            rc = fail(DEFF_EHIP, "hipMemset: %s", hipGetErrorString(he));
+    }
+    if (rc != DEFF_OK) { deff_slab_rank_destroy(s); return rc; }
+    *out = s;
+    return DEFF_OK;
+}
+
+extern "C" int deff_slab_rank_layout(const deff_slab_rank *s, int *first_row, int *row_count)
+{
+    if (!s) return fail(DEFF_EINVAL, "slab is NULL");
+    if (first_row) *first_row = s->g0[s->rank];
+    if (row_count) *row_count = s->own[s->rank];
+    return DEFF_OK;
+}
+
+// the context behind the slab, for deff_set_tuning / deff_assemble_2phase / deff_init_linear
+extern "C" int deff_slab_rank_context(deff_slab_rank *s, deff_ctx **ctx)
+{
+    if (!s || !ctx) return fail(DEFF_EINVAL, "NULL argument");
+    *ctx = s->ctx;
+    return DEFF_OK;
+}
+
+// window = the rows of the whole image this rank's arrays cover (own rows + halo, clipped to the
+// mesh): *first_row, *row_count; the image upload below takes exactly those rows.
+extern "C" int deff_slab_rank_window(const deff_slab_rank *s, int *first_row, int *row_count)
+{
+    if (!s) return fail(DEFF_EINVAL, "slab is NULL");
+    const deff_ctx *c = s->ctx;
+    int a = -c->dom_lo, b = a + c->rows;
+    if (a < 0) a = 0;
+    if (b > s->NY) b = s->NY;
+    if (first_row) *first_row = a;
+    if (row_count) *row_count = b - a;
+    return DEFF_OK;
+}
+
+extern "C" int deff_slab_rank_set_image_window(deff_slab_rank *s, const uint8_t *pix_window)
+{
+    if (!s || !pix_window) return fail(DEFF_EINVAL, "NULL argument");
+    deff_ctx *c = s->ctx;
+    TRY(use_device(c));
+    TRY(image_shape(c, c->nx, c->ny, 1, 1));
+    int a = 0, cnt = 0;
+    TRY(deff_slab_rank_window(s, &a, &cnt));
+    HIP_TRY(hipMemsetAsync(c->pix, 0, c->n, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->pix + (size_t)(a + c->dom_lo) * c->nx, pix_window, (size_t)cnt * c->nx,
+                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_image = true; c->have_matfree = false;
+    return DEFF_OK;
+}
+
+extern "C" int deff_slab_rank_synth_image(deff_slab_rank *s, uint64_t seed, uint64_t img)
+{
+    if (!s) return fail(DEFF_EINVAL, "slab is NULL");
+    deff_ctx *c = s->ctx;
+    TRY(use_device(c));
+    TRY(image_shape(c, c->nx, c->ny, 1, 1));
+    int a = 0, cnt = 0;
+    TRY(deff_slab_rank_window(s, &a, &cnt));
+    HIP_TRY(hipMemsetAsync(c->pix, 0, c->n, c->stream));
+    const uint64_t first = img * (uint64_t)s->NY * (uint64_t)s->nx + (uint64_t)a * (uint64_t)s->nx;
+    hipLaunchKernelGGL(k_synth_mask_at, dim3(grid_for((size_t)cnt * c->nx)), dim3(256), 0, c->stream,
+                       c->pix + (size_t)(a + c->dom_lo) * c->nx, (size_t)cnt * c->nx, seed, first);
+    HIP_TRY(hipGetLastError());
+    c->have_image = true; c->have_matfree = false;
+    return DEFF_OK;
+}
+
+// own rows of the current field -> host
+extern "C" int deff_slab_rank_get_field(deff_slab_rank *s, double *x_own)
+{
+    if (!s || !x_own) return fail(DEFF_EINVAL, "NULL argument");
+    deff_ctx *c = s->ctx;
+    TRY(use_device(c));
+    HIP_TRY(hipMemcpyAsync(x_own, c->x[c->cur] + (size_t)c->own_lo * c->nx, sizeof(double) * (size_t)c->own_h * c->nx,
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DEFF_OK;
+}
+
+static int rank_exchange(deff_slab_rank *s)
+{
+    deff_ctx *c = s->ctx;
+    const size_t blk = (size_t)SLAB_HALO * s->nx;
+    double *x = c->x[c->cur];
+    NCCL_TRY(ncclGroupStart());
+    if (s->rank > 0) {
+        NCCL_TRY(ncclSend(x + (size_t)c->own_lo * s->nx, blk, ncclDouble, s->rank - 1, s->comm, c->stream));
+        NCCL_TRY(ncclRecv(x, blk, ncclDouble, s->rank - 1, s->comm, c->stream));
+    }
+    if (s->rank + 1 < s->nranks) {
+        NCCL_TRY(ncclSend(x + (size_t)(c->own_lo + c->own_h - SLAB_HALO) * s->nx, blk, ncclDouble, s->rank + 1, s->comm,
+                          c->stream));
+        NCCL_TRY(ncclRecv(x + (size_t)(c->own_lo + c->own_h) * s->nx, blk, ncclDouble, s->rank + 1, s->comm, c->stream));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    return DEFF_OK;
+}
+
+static int rank_sweeps(deff_slab_rank *s, const SweepPlan &plT, const SweepPlan &pl1, int64_t n)
+{
+    deff_ctx *c = s->ctx;
+    while (n > 0) {
+        const bool big = n >= plT.T;
+        enqueue_tb_pass(c, big ? plT : pl1);
+        ++c->last_launches;
+        HIP_TRY(hipGetLastError());
+        if (s->nranks > 1) TRY(rank_exchange(s));
+        n -= big ? plT.T : 1;
+    }
+    return DEFF_OK;
+}
+
+static int rank_plans(deff_slab_rank *s, double omega, SweepPlan *plT, SweepPlan *pl1)
+{
+    deff_ctx *c = s->ctx;
+    TRY(use_device(c));
+    if (c->tb_T > SLAB_HALO) return fail(DEFF_EINVAL, "tb_T exceeds the slab halo depth %d", SLAB_HALO);
+    TRY(plan_sweeps(c, omega, plT));
+    if (plT->kernel != DEFF_KERNEL_MATFREE_TB) return fail(DEFF_ESTATE, "row-slab mode needs the temporally blocked kernel");
+    pl1->T_override = 1;
+    TRY(plan_sweeps(c, omega, pl1));
+    c->last_launches = 0;
+    return DEFF_OK;
+}
+
+extern "C" int deff_slab_rank_sweeps(deff_slab_rank *s, int64_t n, double omega, float *ms)
+{
+    if (!s || n < 0) return fail(DEFF_EINVAL, "bad arguments");
+    SweepPlan plT, pl1;
+    TRY(rank_plans(s, omega, &plT, &pl1));
+    deff_ctx *c = s->ctx;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    TRY(rank_sweeps(s, plT, pl1, n));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    if (ms) HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return DEFF_OK;
+}
+
+__global__ void k_pack_own_flux(const double *__restrict__ mf, int rows, int own_lo, int own_h, int maxown,
+                                double *__restrict__ pack)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= own_h) return;
+    pack[i] = mf[own_lo + i];
+    pack[maxown + i] = mf[rows + own_lo + i];
+}
+
+static int rank_flux(deff_slab_rank *s, double *deff_raw)
+{
+    deff_ctx *c = s->ctx;
+    if (!c->have_walls) return fail(DEFF_ESTATE, "wall diffusivities unknown");
+    hipLaunchKernelGGL(k_wall_flux, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, c->x[c->cur], c->Dl, c->Dr,
+                       c->nx, c->rows, c->dx, c->CL, c->CR, c->mf);
+    hipLaunchKernelGGL(k_pack_own_flux, dim3((c->own_h + 255) / 256), dim3(256), 0, c->stream, c->mf, c->rows, c->own_lo,
+                       c->own_h, s->maxown, s->d_pack);
+    HIP_TRY(hipGetLastError());
+    NCCL_TRY(ncclAllGather(s->d_pack, s->d_all, (size_t)2 * s->maxown, ncclDouble, s->comm, c->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_all.data(), s->d_all, sizeof(double) * s->h_all.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < s->nranks; ++r) {
+        const double *blk = s->h_all.data() + (size_t)r * 2 * s->maxown;
+        memcpy(&s->mfl[s->g0[r]], blk, sizeof(double) * s->own[r]);
+        memcpy(&s->mfr[s->g0[r]], blk + s->maxown, sizeof(double) * s->own[r]);
+    }
+    double Q1 = 0, Q2 = 0;
+    for (int j = 0; j < s->NY; ++j) { Q1 += s->mfl[j]; Q2 += s->mfr[j]; }      // global row order, cuh:1258-1259
+    const double qAvg = (Q1 + Q2) / (2.0 * s->NY);
+    *deff_raw = qAvg / ((c->CR - c->CL));
+    return DEFF_OK;
+}
+
+// Collective over the ranks of the communicator: every rank calls it with the same arguments
+// and gets the same result (iters, Deff, conv); MFL/MFR receive the GLOBAL fluxes (NY each).
+extern "C" int deff_slab_rank_solve(deff_slab_rank *s, double omega, double tol, int64_t max_iter, int64_t check_every,
+                                    deff_result *out, double *MFL, double *MFR)
+{
+    if (!s || !out) return fail(DEFF_EINVAL, "NULL argument");
+    if (check_every < 1) return fail(DEFF_EINVAL, "check_every must be >= 1");
+    SweepPlan plT, pl1;
+    TRY(rank_plans(s, omega, &plT, &pl1));
+    deff_ctx *c = s->ctx;
+    int64_t iter = 0, checks = 0;
+    double deffNew = 1, deffOld = 5, change = 100.0, conv = 0;      // cuh:1171-1173
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    while (iter < max_iter && tol < fabs(change)) {                  // cuh:1232
+        const int64_t next_check = ((iter + check_every - 1) / check_every) * check_every;
+        const bool do_check = next_check < max_iter;
+        const int64_t batch = do_check ? next_check - iter + 1 : max_iter - iter;
+        TRY(rank_sweeps(s, plT, pl1, batch));
+        iter += batch;
+        if (do_check) {
+            TRY(rank_flux(s, &deffNew));
+            change = (deffOld - deffNew) / (deffOld);                // cuh:1265
+            deffOld = deffNew;
+            conv = change;
+            ++checks;
+        }
+    }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    out->iters = iter; out->checks = checks; out->deff_raw = deffNew; out->conv = conv; out->loop_ms = ms;
+    if (MFL) memcpy(MFL, s->mfl.data(), sizeof(double) * s->NY);
+    if (MFR) memcpy(MFR, s->mfr.data(), sizeof(double) * s->NY);
     return DEFF_OK;
 }

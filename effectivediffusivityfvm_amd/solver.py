@@ -270,6 +270,91 @@ class SlabGroup:
         return out
 
 
+def rccl_unique_id():
+    """128-byte RCCL id made on rank 0; hand it to every rank's SlabRank."""
+    buf = C.create_string_buffer(128)
+    check(_capi.load().deff_rccl_unique_id(buf))
+    return buf.raw
+
+
+class SlabRank:
+    """This process's slab of one image split over `nranks` processes (one GPU each); halo
+    exchange and flux all-gather go through RCCL.  solve() and sweeps() are collective."""
+
+    def __init__(self, nx, NY, rank, nranks, unique_id, device=0):
+        self._L = _capi.load()
+        self._s = C.c_void_p()
+        self.nx, self.ny, self.rank, self.nranks = int(nx), int(NY), int(rank), int(nranks)
+        check(self._L.deff_slab_rank_create(int(device), self.nx, self.ny, self.rank, self.nranks, unique_id,
+                                            C.byref(self._s)))
+        self._ctx = C.c_void_p()
+        check(self._L.deff_slab_rank_context(self._s, C.byref(self._ctx)))
+
+    def close(self):
+        if self._s:
+            self._L.deff_slab_rank_destroy(self._s)
+            self._s = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _pair(self, fn):
+        a, b = C.c_int(), C.c_int()
+        check(fn(self._s, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def layout(self):
+        """(first owned row, owned rows)"""
+        return self._pair(self._L.deff_slab_rank_layout)
+
+    def window(self):
+        """(first row held incl. halo, rows held): the slice of the image set_image() takes"""
+        return self._pair(self._L.deff_slab_rank_window)
+
+    def set_tuning(self, key, value):
+        check(self._L.deff_set_tuning(self._ctx, key.encode(), int(value)))
+
+    def set_image(self, pix_full):
+        a, n = self.window()
+        win = np.ascontiguousarray(pix_full[a:a + n], dtype=np.uint8)
+        check(self._L.deff_slab_rank_set_image_window(self._s, win))
+
+    def synth_image(self, seed=12345, img=0):
+        check(self._L.deff_slab_rank_synth_image(self._s, seed, img))
+
+    def assemble_2phase(self, Ds, Df, CL, CR):
+        check(self._L.deff_assemble_2phase(self._ctx, Ds, Df, CL, CR))
+
+    def init_linear(self, CL, CR):
+        check(self._L.deff_init_linear(self._ctx, CL, CR))
+
+    def get_field(self):
+        _, own = self.layout()
+        x = np.empty((own, self.nx), dtype=np.float64)
+        check(self._L.deff_slab_rank_get_field(self._s, x))
+        return x
+
+    def sweeps(self, n, omega=OMEGA_REFERENCE):
+        ms = C.c_float()
+        check(self._L.deff_slab_rank_sweeps(self._s, int(n), omega, C.byref(ms)))
+        return ms.value
+
+    def solve(self, tol, max_iter, omega=OMEGA_REFERENCE, check_every=10000):
+        res = Result()
+        MFL = np.zeros(self.ny)
+        MFR = np.zeros(self.ny)
+        check(self._L.deff_slab_rank_solve(self._s, omega, tol, int(max_iter), int(check_every), C.byref(res),
+                                           MFL.ctypes.data_as(C.c_void_p), MFR.ctypes.data_as(C.c_void_p)))
+        out = SolveResult()
+        out.iters, out.checks = res.iters, res.checks
+        out.deff_raw, out.conv, out.loop_ms = res.deff_raw, res.conv, res.loop_ms
+        out.MFL, out.MFR = MFL, MFR
+        return out
+
+
 def flood_fill(grid):
     """FloodFill (Deff2D.cuh:557-713): grid (ny, nx) with 1 = solid -> (grid with unreachable
     pore cells = 2, PathFlag).  Host function of the library; needs no GPU."""
@@ -280,4 +365,4 @@ def flood_fill(grid):
     return g, bool(flag.value)
 
 
-__all__ = ["Solver", "SlabGroup", "flood_fill", "SolveResult", "DeffError", "OMEGA_REFERENCE"]
+__all__ = ["Solver", "SlabGroup", "SlabRank", "rccl_unique_id", "flood_fill", "SolveResult", "DeffError", "OMEGA_REFERENCE"]

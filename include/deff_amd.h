@@ -156,6 +156,25 @@ int deff_slab_group_flux(deff_slab_group *g, double *deff_raw, double *MFL, doub
 int deff_slab_group_solve(deff_slab_group *g, double omega, double tol, int64_t max_iter,
                           int64_t check_every, deff_result *out, double *MFL, double *MFR);
 
+/* ---- row slabs, one process per GPU: same slabs, RCCL transport (grouped ncclSend/ncclRecv of the
+ * 8-row halo blocks between neighbour ranks once per blocked pass; ncclAllGather of the per-row
+ * wall fluxes at a check).  Rank 0 makes the 128-byte id with deff_rccl_unique_id() and hands it
+ * to the others (torch.distributed broadcast, a file, MPI ...).  solve/sweeps are collective. */
+typedef struct deff_slab_rank deff_slab_rank;
+int deff_rccl_unique_id(char *id128);
+int deff_slab_rank_create(int device, int nx, int NY, int rank, int nranks, const char *id128,
+                          deff_slab_rank **out);
+int deff_slab_rank_destroy(deff_slab_rank *s);
+int deff_slab_rank_layout(const deff_slab_rank *s, int *first_row, int *row_count);   /* rows it owns */
+int deff_slab_rank_window(const deff_slab_rank *s, int *first_row, int *row_count);   /* rows it holds */
+int deff_slab_rank_context(deff_slab_rank *s, deff_ctx **ctx);   /* for set_tuning / assemble_2phase / init_linear */
+int deff_slab_rank_set_image_window(deff_slab_rank *s, const uint8_t *pix_window);
+int deff_slab_rank_synth_image(deff_slab_rank *s, uint64_t seed, uint64_t img);
+int deff_slab_rank_get_field(deff_slab_rank *s, double *x_own);
+int deff_slab_rank_sweeps(deff_slab_rank *s, int64_t n, double omega, float *ms);
+int deff_slab_rank_solve(deff_slab_rank *s, double omega, double tol, int64_t max_iter,
+                         int64_t check_every, deff_result *out, double *MFL, double *MFR);
+
 /* raw device pointers for zero-copy interop (torch tensors, RCCL): current field,
  * and the byte pitch between rows (nx*8: rows are dense) */
 int deff_device_field(deff_ctx *ctx, void **d_x, size_t *row_pitch_bytes);

@@ -376,6 +376,75 @@ def test_row_slabs_4096_equals_one_gpu(pkg, recorded):
         assert np.array_equal(g.get_field(), ref)
 
 
+def test_rccl_slab_single_rank(pkg, oracle):
+    """The process-per-GPU transport with a communicator of one rank (all a one-GPU box allows):
+    RCCL init, the all-gather of the fluxes, the solve loop; no neighbour to exchange with."""
+    nx, NY = 128, 96
+    rng = np.random.default_rng(3)
+    pix = rand_mask(rng, nx, NY, 0.5)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-2)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    it, deff, conv, x, MFL, MFR = oracle.jacobi(A, b, oracle.linear_guess(nx, NY, 0.0, 1.0), D, 0.0, 1.0, 1e-3,
+                                                2000, check_every=100)
+    with pkg.SlabRank(nx, NY, 0, 1, pkg.rccl_unique_id()) as s:
+        assert s.layout() == (0, NY) and s.window() == (0, NY)
+        s.set_image(pix)
+        s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        r = s.solve(1e-3, 2000, check_every=100)
+        assert (r.iters, r.deff_raw, r.conv) == (it, deff, conv)
+        assert_field(s.get_field(), x)
+        assert np.array_equal(r.MFL, MFL)
+
+
+def _rccl_slab_worker(rank, world, idfile, nx, NY, out_dir):
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import time
+    import effectivediffusivityfvm_amd as pkg
+    if rank == 0:
+        uid = pkg.rccl_unique_id()
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(uid)
+        os.rename(idfile + ".tmp", idfile)
+    else:
+        while not os.path.exists(idfile):
+            time.sleep(0.05)
+        uid = open(idfile, "rb").read()
+    pix = np.load(os.path.join(out_dir, "pix.npy"))
+    with pkg.SlabRank(nx, NY, rank, world, uid, device=rank) as s:
+        s.set_image(pix)
+        s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        r = s.solve(1e-3, 2000, check_every=100)
+        np.save(os.path.join(out_dir, f"x{rank}.npy"), s.get_field())
+        np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([r.iters, r.deff_raw, r.conv]))
+
+
+def test_rccl_slabs_two_ranks(pkg, oracle, tmp_path):
+    """Two processes, two GPUs, RCCL halo exchange: needs a multi-GPU box (skipped on one GPU)."""
+    import subprocess
+    n = int(subprocess.run(["python3", "-c", "import torch; print(torch.cuda.device_count())"],
+                           capture_output=True, text=True).stdout.strip() or 0)
+    if n < 2:
+        pytest.skip("needs 2 GPUs")
+    import torch.multiprocessing as mp
+    nx, NY = 256, 200
+    rng = np.random.default_rng(5)
+    pix = rand_mask(rng, nx, NY, 0.5)
+    np.save(tmp_path / "pix.npy", pix)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-2)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    it, deff, conv, x, _, _ = oracle.jacobi(A, b, oracle.linear_guess(nx, NY, 0.0, 1.0), D, 0.0, 1.0, 1e-3, 2000,
+                                            check_every=100)
+    mp.spawn(_rccl_slab_worker, args=(2, str(tmp_path / "id"), nx, NY, str(tmp_path)), nprocs=2, join=True)
+    got = np.concatenate([np.load(tmp_path / "x0.npy"), np.load(tmp_path / "x1.npy")])
+    assert_field(got, x)
+    for k in range(2):
+        assert tuple(np.load(tmp_path / f"r{k}.npy")) == (it, deff, conv)
+
+
 def test_host_assembled_system_drop_in(pkg, oracle):
     """The reference's own arrays (A AoS, b, D) go in unchanged: set_system + solve."""
     rng = np.random.default_rng(11)
