@@ -7,4 +7,4 @@ the library or a device is missing.
 """
 from ._capi import DeffError, KERNEL_NAMES, LIB_PATH  # noqa: F401
 from .solver import (OMEGA_REFERENCE, SlabGroup, SlabRank, Solver, SolveResult, flood_fill,  # noqa: F401
-                     rccl_unique_id)
+                     load_jpeg_gray, rccl_unique_id)

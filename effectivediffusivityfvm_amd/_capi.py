@@ -19,7 +19,7 @@ SYMBOLS = [
     "deff_version", "deff_last_error", "deff_error_string", "deff_device_count",
     "deff_create", "deff_create_batch", "deff_batch_size", "deff_destroy", "deff_mesh", "deff_set_kernel", "deff_get_kernel",
     "deff_set_tuning", "deff_set_image", "deff_synth_image", "deff_get_image",
-    "deff_assemble_2phase", "deff_assemble_3phase", "deff_flood_fill", "deff_assemble_from_D", "deff_set_system", "deff_get_system",
+    "deff_load_jpeg_gray", "deff_free", "deff_assemble_2phase", "deff_assemble_3phase", "deff_flood_fill", "deff_assemble_from_D", "deff_set_system", "deff_get_system",
     "deff_init_linear", "deff_set_field", "deff_get_field", "deff_solve", "deff_solve_batch", "deff_sweeps",
     "deff_slab_group_create", "deff_slab_group_destroy", "deff_slab_group_layout", "deff_slab_group_set_tuning",
     "deff_slab_group_set_image", "deff_slab_group_synth_image", "deff_slab_group_assemble_2phase",
@@ -77,6 +77,10 @@ def load():
     L.deff_set_image.argtypes = [ctx, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.deff_synth_image.argtypes = [ctx, C.c_uint64, C.c_uint64]
     L.deff_get_image.argtypes = [ctx, _u8p]
+    L.deff_load_jpeg_gray.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int)]
+    L.deff_free.argtypes = [C.c_void_p]
+    L.deff_free.restype = None
     L.deff_assemble_2phase.argtypes = [ctx, C.c_double, C.c_double, C.c_double, C.c_double]
     L.deff_assemble_3phase.argtypes = [ctx, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_double,
                                        C.c_double]

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/deff_amd.h"
+#include "driver/jpeg_gray.hpp"
 #include "flood_fill.hpp"
 #include "fvm_row.hpp"
 #include "kernels_setup.hpp"
@@ -536,6 +537,27 @@ extern "C" int deff_flood_fill(unsigned int *Grid, int nx, int ny, int *path_fla
     if (path_flag) *path_flag = flag;
     return DEFF_OK;
 }
+
+// Grayscale JPEG -> bytes, the reference's readImage (cuh:327-345: stbi_load(name,&w,&h,&n,1)).
+// *pix is malloc'ed (release with deff_free); *nChannels is the file's component count and is set
+// even when the call fails because the image is not single-channel (the reference's check).
+extern "C" int deff_load_jpeg_gray(const char *path, uint8_t **pix, int *W, int *H, int *nChannels)
+{
+    if (!path || !pix || !W || !H) return fail(DEFF_EINVAL, "NULL argument");
+    std::vector<uint8_t> buf;
+    std::string err;
+    int n = 0;
+    *pix = nullptr;
+    const bool ok = jpeg::load_gray(path, buf, *W, *H, n, err);
+    if (nChannels) *nChannels = n;
+    if (!ok) return fail(DEFF_EINVAL, "%s: %s", path, err.c_str());
+    *pix = (uint8_t *)malloc(buf.size());
+    if (!*pix) return fail(DEFF_ENOMEM, "host allocation failed");
+    memcpy(*pix, buf.data(), buf.size());
+    return DEFF_OK;
+}
+
+extern "C" void deff_free(void *p) { free(p); }
 
 // Host -> device in bounded chunks through the scratch buffer.
 static const size_t CHUNK_CELLS = (size_t)1 << 22;   // 4 Mi cells

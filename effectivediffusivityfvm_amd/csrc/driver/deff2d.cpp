@@ -1,0 +1,322 @@
+// deff2d -- command-line driver with the reference's front end and outputs.
+//
+// Reads the reference's input.txt (same keys), loads the same grayscale JPEGs (decoded to the
+// same bytes as stb_image, see jpeg_gray.hpp), runs the four modes of the reference's main
+// (Deff2DGPU/Deff2D.cu:17-50) -- {2,3} phases x {single image, numbered batch} -- on the native
+// GPU path of libdeff_amd (pixels up, everything else on the device), and writes the
+// reference's CSV rows (cuh:177-232) and concentration maps (cuh:497-554).  Because those
+// formats keep only 4-7 digits, --json also writes every result at full precision and
+// --field-bin dumps the FP64 concentration field.
+//
+//   deff2d [input.txt] [--device N] [--json results.json] [--field-bin prefix] [--batch-size B]
+//
+// This is host-side orchestration only; all arithmetic of the hot path happens behind the C ABI.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/deff_amd.h"
+#include "input_file.hpp"
+#include "jpeg_gray.hpp"
+
+using deff::Options;
+
+struct Image {
+    std::vector<uint8_t> pix;
+    int W = 0, H = 0, nChannels = 0;
+};
+
+struct Row {                       // one output row (2-phase: porosity; 3-phase: SVF/LVF)
+    std::string name;
+    double porosity = 0, SVF = 0, LVF = 0, deff = NAN, seconds = 0, conv = NAN;
+    int path = 0, nElements = 0;
+    long iters = 0;
+    std::vector<long> stages;
+};
+
+#define CK(expr)                                                                              \
+    do {                                                                                      \
+        int rc_ = (expr);                                                                     \
+        if (rc_ != DEFF_OK) {                                                                 \
+            std::fprintf(stderr, "deff2d: %s: %s (%s)\n", #expr, deff_last_error(), deff_error_string(rc_)); \
+            return false;                                                                     \
+        }                                                                                     \
+    } while (0)
+
+static bool load_image(const std::string &path, Image *img)
+{
+    std::string err;
+    if (!deff::jpeg::load_gray(path.c_str(), img->pix, img->W, img->H, img->nChannels, err)) {
+        if (img->nChannels > 1)     // the reference's message, cuh:1665-1667
+            std::printf("Error: please enter a grascale image with 1 channel.\n Current number of channels = %d\n",
+                        img->nChannels);
+        else
+            std::fprintf(stderr, "deff2d: %s: %s\n", path.c_str(), err.c_str());
+        return false;
+    }
+    return true;
+}
+
+static double porosity_of(const Image &im)                         // calcPorosity, cuh:383-408
+{
+    const double total = (double)im.H * im.W;
+    double p = 0;
+    for (size_t k = 0; k < im.pix.size(); ++k)
+        if (im.pix[k] < 150) p += 1.0 / total;
+    return p;
+}
+
+// Grid over the mesh for FloodFill.  (The reference indexes the image with mesh-sized loop
+// bounds here, cuh:1921-1926, which is only well defined for MeshAmp 1; the amplified lookup
+// below is what it evidently means.)
+static std::vector<unsigned int> grid_of(const Image &im, const Options &o, int threshold)
+{
+    const int nx = im.W * o.MeshIncreaseX, ny = im.H * o.MeshIncreaseY;
+    std::vector<unsigned int> g((size_t)nx * ny);
+    for (int i = 0; i < ny; ++i)
+        for (int j = 0; j < nx; ++j)
+            g[(size_t)i * nx + j] = im.pix[(size_t)(i / o.MeshIncreaseY) * im.W + j / o.MeshIncreaseX] > threshold ? 1u : 0u;
+    return g;
+}
+
+struct Session {                   // one solver context, re-created only when the mesh changes
+    deff_ctx *ctx = nullptr;
+    int nx = 0, ny = 0, device = 0;
+    ~Session() { deff_destroy(ctx); }
+    bool prepare(int nx_, int ny_)
+    {
+        if (ctx && nx == nx_ && ny == ny_) return true;
+        deff_destroy(ctx);
+        ctx = nullptr;
+        CK(deff_create(device, nx_, ny_, &ctx));
+        nx = nx_; ny = ny_;
+        return true;
+    }
+};
+
+static void progress(int64_t iter, double deff, double change, void *user)
+{
+    std::printf("Iteration = %d, Deff = %1.3e, Deff Change = %1.3e\n", (int)iter, deff / *(double *)user, change);   // cuh:1270
+}
+
+// 2-phase image.  single = SingleSim's DCF ramp 100, 1e4, ... up to Df (cuh:1759-1817);
+// batch = BatchSim: one solve with Df (cuh:1939-2017).
+static bool solve_2phase(Session &S, const Image &im, const Options &o, bool single, Row *row, std::vector<double> *field)
+{
+    const int nx = im.W * o.MeshIncreaseX, ny = im.H * o.MeshIncreaseY;
+    if (!S.prepare(nx, ny)) return false;
+    row->nElements = nx * ny;
+    row->porosity = porosity_of(im);
+    std::vector<unsigned int> grid = grid_of(im, o, 150);
+    CK(deff_flood_fill(grid.data(), nx, ny, &row->path));
+    CK(deff_set_image(S.ctx, im.pix.data(), im.W, im.H, o.MeshIncreaseX, o.MeshIncreaseY));
+    CK(deff_init_linear(S.ctx, o.CLeft, o.CRight));
+    double ms_total = 0;
+    auto stage = [&](double DCF) -> bool {
+        CK(deff_assemble_2phase(S.ctx, o.DCsolid, DCF, o.CLeft, o.CRight));
+        deff_result r;
+        double scale = DCF;
+        if (o.verbose == 1 && !o.BatchFlag) deff_set_progress(S.ctx, progress, &scale);
+        CK(deff_solve(S.ctx, 2.0 / 3.0, o.ConvergeCriteria, o.MAX_ITER, 10000, &r, nullptr, nullptr));
+        deff_set_progress(S.ctx, nullptr, nullptr);
+        if (o.verbose == 1) std::printf("Iterations taken = %ld\n", (long)r.iters);
+        row->deff = r.deff_raw / DCF;                                 // cuh:1802 / cuh:2017
+        row->conv = r.conv;
+        row->iters = (long)r.iters;
+        row->stages.push_back((long)r.iters);
+        ms_total += r.loop_ms;
+        if (o.verbose == 1) std::printf("DCF = %g, Deff %g\n", DCF, row->deff);
+        return true;
+    };
+    if (single) {
+        const double DCF_Max = o.DCfluid;
+        double DCF = 10.0;
+        int count = 1, ran = 0;
+        while (DCF <= DCF_Max) {                                     // cuh:1761
+            DCF = std::pow(100, count);
+            if (DCF >= DCF_Max) DCF = DCF_Max;
+            if (!stage(DCF)) return false;
+            ++ran;
+            if (DCF == DCF_Max) break;
+            ++count;
+        }
+        if (!ran) {
+            // The reference's loop does not execute for Df < 10 and its CSV row then holds
+            // uninitialised memory.  Solve once with Df instead, and say so.
+            std::fprintf(stderr, "deff2d: note: Df = %g < 10: the reference's single-image ramp runs no solve here; "
+                                 "solving directly with Df (as RunBatch: 1 does)\n", o.DCfluid);
+            if (!stage(o.DCfluid)) return false;
+        }
+    } else {
+        if (!stage(o.DCfluid)) return false;
+    }
+    row->seconds = ms_total / 1000.0;
+    if (field) { field->resize((size_t)nx * ny); CK(deff_get_field(S.ctx, field->data())); }
+    return true;
+}
+
+// 3-phase image: FloodFill on pixels > 200, DCG continuation (cuh:1443-1597).
+static bool solve_3phase(Session &S, const Image &im, const Options &o, Row *row, std::vector<double> *field)
+{
+    const int nx = im.W * o.MeshIncreaseX, ny = im.H * o.MeshIncreaseY;
+    if (!S.prepare(nx, ny)) return false;
+    row->nElements = nx * ny;
+    std::vector<unsigned int> grid = grid_of(im, o, 200);
+    CK(deff_flood_fill(grid.data(), nx, ny, &row->path));
+    CK(deff_set_image(S.ctx, im.pix.data(), im.W, im.H, o.MeshIncreaseX, o.MeshIncreaseY));
+    CK(deff_init_linear(S.ctx, o.CLeft, o.CRight));
+    const double DCF = o.DCfluid, DCG = o.DCgas, DCS = o.DCsolid;
+    int stage_no = 1;
+    for (double g = 10; g < DCG; g *= 10, ++stage_no) {              // JacobiGPUPreCond stages, cuh:1492-1549
+        if (o.verbose == 1) std::printf("Pre-Cond Stage %d: DCG = %1.3e\n", stage_no, g);
+        CK(deff_assemble_3phase(S.ctx, DCS, DCF, g, grid.data(), o.CLeft, o.CRight));
+        deff_result r;
+        CK(deff_solve(S.ctx, 2.0 / 3.0, o.ConvergeCriteria * 10, 1000000, 10000, &r, nullptr, nullptr));
+        if (o.verbose == 1) std::printf("Iterations taken = %ld\n", (long)r.iters);
+        row->stages.push_back((long)r.iters);
+    }
+    // volume fractions by exact comparison of D with the phase values (calcFracts3D, cuh:411-448)
+    {
+        const double total = (double)nx * ny;
+        double s = 0, l = 0;
+        for (int i = 0; i < ny; ++i)
+            for (int j = 0; j < nx; ++j) {
+                const uint8_t v = im.pix[(size_t)(i / o.MeshIncreaseY) * im.W + j / o.MeshIncreaseX];
+                const double D = v > 200 ? DCS : (v < 50 ? DCG : DCF);
+                if (D == DCS) s += 1.0 / total;
+                else if (D == DCF) l += 1.0 / total;
+            }
+        row->SVF = s; row->LVF = l;
+    }
+    CK(deff_assemble_3phase(S.ctx, DCS, DCF, DCG, grid.data(), o.CLeft, o.CRight));
+    deff_result r;
+    double scale = DCF;
+    if (o.verbose == 1 && !o.BatchFlag) deff_set_progress(S.ctx, progress, &scale);
+    CK(deff_solve(S.ctx, 2.0 / 3.0, o.ConvergeCriteria, o.MAX_ITER, 10000, &r, nullptr, nullptr));
+    deff_set_progress(S.ctx, nullptr, nullptr);
+    if (o.verbose == 1) std::printf("Iterations taken = %ld\n", (long)r.iters);
+    row->stages.push_back((long)r.iters);
+    row->iters = (long)r.iters;
+    row->deff = r.deff_raw / DCF;                                     // cuh:1601
+    row->conv = r.conv;
+    row->seconds = r.loop_ms / 1000.0;                                // JacobiGPUPreCond does not add to gpuTime, cuh:1147
+    if (o.verbose == 1) std::printf("DCF = %g, Deff %g\n", DCF, row->deff);
+    if (field) { field->resize((size_t)nx * ny); CK(deff_get_field(S.ctx, field->data())); }
+    return true;
+}
+
+static void write_cmap(const std::string &name, const std::vector<double> &x, int nx, int ny)   // createCMAP, cuh:497-524
+{
+    FILE *f = std::fopen(name.c_str(), "w+");
+    if (!f) { std::fprintf(stderr, "deff2d: cannot write %s\n", name.c_str()); return; }
+    std::fprintf(f, "X,Y,C\n");
+    for (int i = 0; i < ny; ++i)
+        for (int j = 0; j < nx; ++j) std::fprintf(f, "%d,%d,%1.3e\n", j, i, x[(size_t)i * nx + j]);
+    std::fclose(f);
+}
+
+static void write_csv(const Options &o, const std::vector<Row> &rows)
+{
+    FILE *f = std::fopen(o.outputFilename.c_str(), "a+");           // append, header every run: cuh:182-183
+    if (!f) { std::fprintf(stderr, "deff2d: cannot write %s\n", o.outputFilename.c_str()); return; }
+    if (o.nPhase == 2) {
+        std::fprintf(f, "imgNum,porosity,PathFlag,Deff,Time,nElements,converge,ds,df\n");
+        for (size_t k = 0; k < rows.size(); ++k) {
+            const Row &r = rows[k];
+            if (o.BatchFlag) std::fprintf(f, "%d,", (int)k); else std::fprintf(f, "%s,", r.name.c_str());
+            std::fprintf(f, "%f,%d,%f,%f,%d,%f,%f,%f\n", r.porosity, r.path, r.deff, r.seconds, r.nElements, r.conv,
+                         o.DCsolid, o.DCfluid);
+        }
+    } else {
+        std::fprintf(f, "imgNum,SVF,LVF,PathFlag,Deff,Time,nElements,converge,ds,df,dg\n");
+        for (size_t k = 0; k < rows.size(); ++k) {
+            const Row &r = rows[k];
+            if (o.BatchFlag)                                         // cuh:228-229
+                std::fprintf(f, "%d,%f,%f,%d,%1.5e,%f,%d,%1.5e,%1.5e,%1.5e,%1.5e\n", (int)k, r.SVF, r.LVF, r.path, r.deff,
+                             r.seconds, r.nElements, r.conv, o.DCsolid, o.DCfluid, o.DCgas);
+            else                                                     // cuh:198-199
+                std::fprintf(f, "%s,%f,%f,%d,%1.3e,%f,%d,%1.3e,%1.3e,%1.3e,%1.3e\n", r.name.c_str(), r.SVF, r.LVF, r.path,
+                             r.deff, r.seconds, r.nElements, r.conv, o.DCsolid, o.DCfluid, o.DCgas);
+        }
+    }
+    std::fclose(f);
+}
+
+static void write_json(const std::string &path, const Options &o, const std::vector<Row> &rows)
+{
+    FILE *f = std::fopen(path.c_str(), "w");
+    if (!f) { std::fprintf(stderr, "deff2d: cannot write %s\n", path.c_str()); return; }
+    std::fprintf(f, "{\"phases\": %d, \"results\": [\n", o.nPhase);
+    for (size_t k = 0; k < rows.size(); ++k) {
+        const Row &r = rows[k];
+        std::fprintf(f, "  {\"image\": \"%s\", \"porosity\": %.17g, \"SVF\": %.17g, \"LVF\": %.17g, \"PathFlag\": %d, ", r.name.c_str(),
+                     r.porosity, r.SVF, r.LVF, r.path);
+        if (std::isfinite(r.deff)) std::fprintf(f, "\"Deff\": %.17g, ", r.deff); else std::fprintf(f, "\"Deff\": null, ");
+        if (std::isfinite(r.conv)) std::fprintf(f, "\"converge\": %.17g, ", r.conv); else std::fprintf(f, "\"converge\": null, ");
+        std::fprintf(f, "\"iterations\": %ld, \"stage_iterations\": [", r.iters);
+        for (size_t q = 0; q < r.stages.size(); ++q) std::fprintf(f, "%s%ld", q ? ", " : "", r.stages[q]);
+        std::fprintf(f, "], \"Time\": %.9g, \"nElements\": %d}%s\n", r.seconds, r.nElements, k + 1 < rows.size() ? "," : "");
+    }
+    std::fprintf(f, "]}\n");
+    std::fclose(f);
+}
+
+int main(int argc, char **argv)
+{
+    std::string input = "input.txt", json, field_prefix;            // fixed name in the reference, Deff2D.cu:13
+    int device = 0;
+    for (int a = 1; a < argc; ++a) {
+        const std::string s = argv[a];
+        if (s == "--device" && a + 1 < argc) device = std::atoi(argv[++a]);
+        else if (s == "--json" && a + 1 < argc) json = argv[++a];
+        else if (s == "--field-bin" && a + 1 < argc) field_prefix = argv[++a];
+        else if (s == "-h" || s == "--help") {
+            std::printf("usage: deff2d [input.txt] [--device N] [--json results.json] [--field-bin prefix]\n");
+            return 0;
+        } else if (!s.empty() && s[0] != '-') input = s;
+        else { std::fprintf(stderr, "deff2d: unknown argument %s\n", s.c_str()); return 2; }
+    }
+    Options o;
+    std::string err;
+    if (!deff::read_input_file(input.c_str(), &o, &err)) { std::fprintf(stderr, "deff2d: %s\n", err.c_str()); return 1; }
+    if (o.verbose == 1) deff::print_options(o);
+
+    Session S;
+    S.device = device;
+    const int count = o.BatchFlag ? o.NumImg : 1;
+    std::vector<Row> rows;
+    const bool want_field = o.printCmap == 1 || !field_prefix.empty();
+    for (int k = 0; k < count; ++k) {
+        char numbered[32];
+        std::snprintf(numbered, sizeof numbered, "%05d.jpg", k);     // cuh:1876
+        const std::string name = o.BatchFlag ? std::string(numbered) : o.inputFilename;
+        Image im;
+        if (!load_image(name, &im)) return 1;
+        Row row;
+        row.name = name;
+        if (o.verbose == 1) std::printf("Width = %d Height = %d Channel = %d\n", im.W, im.H, im.nChannels);
+        std::vector<double> field;
+        const bool ok = (o.nPhase == 2) ? solve_2phase(S, im, o, !o.BatchFlag, &row, want_field ? &field : nullptr)
+                                        : solve_3phase(S, im, o, &row, want_field ? &field : nullptr);
+        if (!ok) return 1;
+        if (o.verbose == 1 && o.nPhase == 2) std::printf("Porosity = %g\n", row.porosity);
+        const int nx = im.W * o.MeshIncreaseX, ny = im.H * o.MeshIncreaseY;
+        if (o.printCmap == 1) {
+            char cm[32];
+            std::snprintf(cm, sizeof cm, "CMAP_%05d.csv", k);        // batch naming, cuh:2387
+            write_cmap(o.BatchFlag ? std::string(cm) : o.CMapName, field, nx, ny);
+        }
+        if (!field_prefix.empty()) {
+            char fn[512];
+            std::snprintf(fn, sizeof fn, "%s_%05d_%dx%d.f64", field_prefix.c_str(), k, nx, ny);
+            if (FILE *f = std::fopen(fn, "wb")) { std::fwrite(field.data(), sizeof(double), field.size(), f); std::fclose(f); }
+        }
+        rows.push_back(row);
+    }
+    write_csv(o, rows);                                              // after ALL images, like the reference (cuh:2051)
+    if (!json.empty()) write_json(json, o, rows);
+    return 0;
+}

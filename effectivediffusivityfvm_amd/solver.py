@@ -355,6 +355,18 @@ class SlabRank:
         return out
 
 
+def load_jpeg_gray(path):
+    """Grayscale JPEG -> uint8 (H, W), decoded like the reference's stbi_load(..., 1)."""
+    L = _capi.load()
+    p = C.c_void_p()
+    w, h, n = C.c_int(), C.c_int(), C.c_int()
+    check(L.deff_load_jpeg_gray(str(path).encode(), C.byref(p), C.byref(w), C.byref(h), C.byref(n)))
+    try:
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h.value, w.value)).copy()
+    finally:
+        L.deff_free(p)
+
+
 def flood_fill(grid):
     """FloodFill (Deff2D.cuh:557-713): grid (ny, nx) with 1 = solid -> (grid with unreachable
     pore cells = 2, PathFlag).  Host function of the library; needs no GPU."""
@@ -365,4 +377,4 @@ def flood_fill(grid):
     return g, bool(flag.value)
 
 
-__all__ = ["Solver", "SlabGroup", "SlabRank", "rccl_unique_id", "flood_fill", "SolveResult", "DeffError", "OMEGA_REFERENCE"]
+__all__ = ["Solver", "SlabGroup", "SlabRank", "rccl_unique_id", "flood_fill", "load_jpeg_gray", "SolveResult", "DeffError", "OMEGA_REFERENCE"]

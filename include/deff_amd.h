@@ -84,6 +84,12 @@ int deff_set_image(deff_ctx *ctx, const uint8_t *pix, int W, int H, int ampX, in
 int deff_synth_image(deff_ctx *ctx, uint64_t seed, uint64_t img);   /* generated on the device */
 int deff_get_image(deff_ctx *ctx, uint8_t *pix);                    /* W*H bytes back */
 
+/* grayscale JPEG file -> bytes: replaces readImage cuh:327-345 (stbi_load(..., 1)); decodes to the
+ * same bytes as stb_image v2.26 for baseline one-component files; *pix is malloc'ed, release it
+ * with deff_free(); host code, needs no context */
+int deff_load_jpeg_gray(const char *path, uint8_t **pix, int *W, int *H, int *nChannels);
+void deff_free(void *p);
+
 /* ---- assembly: replaces DiscretizeMatrix2D cuh:815-902 (+ WeightedHarmonicMean cuh:347-360) */
 /* native 2-phase path: image already on the device, coefficients never leave it */
 int deff_assemble_2phase(deff_ctx *ctx, double Ds, double Df, double CL, double CR);

@@ -1,0 +1,136 @@
+"""Front end either side of the hot path: JPEG decoding (the reference decodes with stb_image),
+input.txt parsing and the command-line driver's outputs."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+EXE = os.path.join(ROOT, "effectivediffusivityfvm_amd", "deff2d")
+
+
+@pytest.fixture(scope="module")
+def built():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "effectivediffusivityfvm_amd", "csrc")], check=True)
+    assert os.access(EXE, os.X_OK)
+    return EXE
+
+
+def test_jpeg_decoder_matches_stb_image_statistics(built):
+    """SURVEY.md section 5 measured stb_image (the reference's decoder) against libjpeg on this
+    file: they differ by +-1 on exactly 41 pixels, none across a phase threshold.  The decoder
+    here must show exactly that signature against PIL's libjpeg, and the recorded porosity."""
+    import effectivediffusivityfvm_amd as pkg
+    from PIL import Image
+    mine = pkg.load_jpeg_gray(os.path.join(GOLDEN, "00000.jpg"))
+    ref = np.array(Image.open(os.path.join(GOLDEN, "00000.jpg")), dtype=np.uint8)
+    assert mine.shape == (128, 128)
+    d = mine.astype(int) - ref.astype(int)
+    assert np.abs(d).max() == 1 and int((d != 0).sum()) == 41
+    for thr in (50, 150, 200):
+        assert np.array_equal(mine < thr, ref < thr)
+    assert float((mine < 150).mean()) == 0.3460693359375
+    # the committed pixel fixture (PIL-decoded) gives the same phases
+    assert np.array_equal(np.load(os.path.join(GOLDEN, "img00000_pix.npy")) < 150, mine < 150)
+
+
+def test_jpeg_decoder_on_second_reference_image(built):
+    """00042.jpg (1002x2007, not committed: 771 KB): stb_image vs libjpeg differ on 9 809 pixels and
+    364-378 of them cross the 150 threshold.  Only runs where the reference is mounted."""
+    path = "/root/reference/Deff2DGPU/00042.jpg"
+    if not os.path.exists(path):
+        pytest.skip("reference not mounted")
+    import effectivediffusivityfvm_amd as pkg
+    from PIL import Image
+    mine = pkg.load_jpeg_gray(path)
+    ref = np.array(Image.open(path), dtype=np.uint8)
+    assert mine.shape == (2007, 1002)
+    d = mine.astype(int) - ref.astype(int)
+    assert np.abs(d).max() == 1 and int((d != 0).sum()) == 9809
+    assert 364 <= int(((mine < 150) != (ref < 150)).sum()) <= 378
+    assert np.array_equal(mine < 50, ref < 50) and np.array_equal(mine > 200, ref > 200)
+
+
+def test_jpeg_decoder_rejects_what_the_reference_rejects(built, tmp_path):
+    import effectivediffusivityfvm_amd as pkg
+    from PIL import Image
+    rgb = tmp_path / "rgb.jpg"
+    Image.fromarray(np.zeros((16, 16, 3), dtype=np.uint8)).save(rgb)
+    with pytest.raises(pkg.DeffError, match="single-channel"):
+        pkg.load_jpeg_gray(rgb)
+    with pytest.raises(pkg.DeffError):
+        pkg.load_jpeg_gray(tmp_path / "missing.jpg")
+    # odd sizes (partial MCUs) and restart markers decode like libjpeg up to the IDCT rounding
+    rng = np.random.default_rng(0)
+    img = (rng.random((37, 53)) * 255).astype(np.uint8)
+    p = tmp_path / "odd.jpg"
+    Image.fromarray(img).save(p, quality=90)
+    mine = pkg.load_jpeg_gray(p)
+    ref = np.array(Image.open(p), dtype=np.uint8)
+    assert mine.shape == (37, 53) and np.abs(mine.astype(int) - ref.astype(int)).max() <= 1
+
+
+def _write_input(path, **kv):
+    lines = ["Input File:"] + [f"{k}: {v}" for k, v in kv.items()]
+    open(path, "w").write("\n".join(lines) + "\n")
+
+
+def test_driver_input_errors_without_gpu(built, tmp_path):
+    r = subprocess.run([EXE, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "usage" in r.stdout
+    r = subprocess.run([EXE, str(tmp_path / "nope.txt")], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot open" in r.stderr
+    _write_input(tmp_path / "bad.txt", Phases=4)
+    r = subprocess.run([EXE, str(tmp_path / "bad.txt")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Phases" in r.stderr
+    _write_input(tmp_path / "amp.txt", Phases=2, MeshAmpX=0)
+    r = subprocess.run([EXE, str(tmp_path / "amp.txt")], capture_output=True, text=True)
+    assert r.returncode == 1 and "MeshIncrease" in r.stderr
+
+
+@pytest.mark.gpu
+def test_driver_2phase_batch_config1(built, tmp_path, recorded):
+    """Config #1 through the command line: the reference's input.txt keys, 00000.jpg, RunBatch 1."""
+    shutil.copy(os.path.join(GOLDEN, "00000.jpg"), tmp_path / "00000.jpg")
+    _write_input(tmp_path / "input.txt", Phases=2, Ds="1e-3", Df=1, MeshAmpX=1, MeshAmpY=1, CR=1, CL=0,
+                 OutputName="out.csv", printCMap=0, Convergence="1e-6", MaxIter="5e5", Verbose=0, RunBatch=1,
+                 NumImages=1)
+    r = subprocess.run([EXE, "input.txt", "--json", "res.json", "--field-bin", "field"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    res = json.load(open(tmp_path / "res.json"))["results"][0]
+    rec = recorded["img00000_2phase_batch"]
+    assert res["iterations"] == rec["iters"] and res["porosity"] == rec["porosity"] and res["PathFlag"] == 1
+    assert res["Deff"] in (rec["deff_build_a"], rec["deff_build_b"])
+    rows = open(tmp_path / "out.csv").read().splitlines()
+    assert rows[0] == "imgNum,porosity,PathFlag,Deff,Time,nElements,converge,ds,df"
+    cols = rows[1].split(",")
+    assert cols[0] == "0" and cols[1] == "0.346069" and cols[2] == "1" and cols[3] == "0.182862" and cols[5] == "16384"
+    field = np.fromfile(tmp_path / "field_00000_128x128.f64").reshape(128, 128)
+    gold = np.load(os.path.join(GOLDEN, "img00000_field.npy"))
+    assert np.linalg.norm(field - gold) / np.linalg.norm(gold) <= 1e-6 and np.array_equal(field, gold)
+
+
+@pytest.mark.gpu
+def test_driver_3phase_as_shipped(built, tmp_path, recorded):
+    """The reference's shipped input.txt, pointed at 00000.jpg: 3 phases, DCG continuation."""
+    shutil.copy(os.path.join(GOLDEN, "00000.jpg"), tmp_path / "00000.jpg")
+    _write_input(tmp_path / "input.txt", Phases=3, Ds=0, Df=1, Dg=1237500, MeshAmpX=1, MeshAmpY=1,
+                 InputName="00000.jpg", CR=1, CL=0, OutputName="singleTest.csv", printCMap=1, CMapName="CMAP.csv",
+                 Convergence="1e-5", MaxIter="5e5", Verbose=1, RunBatch=0, NumImages=500)
+    r = subprocess.run([EXE, "--json", "res.json"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    rec = recorded["img00000_3phase_as_shipped"]
+    res = json.load(open(tmp_path / "res.json"))["results"][0]
+    assert res["stage_iterations"] == rec["stage_sweeps"]
+    assert res["Deff"] == rec["deff"] and res["converge"] == rec["conv"] and res["SVF"] == rec["SVF"]
+    assert "Pre-Cond Stage 6: DCG = 1.000e+06" in r.stdout and "Iteration = 0, Deff = " in r.stdout
+    rows = open(tmp_path / "singleTest.csv").read().splitlines()
+    assert rows[0] == "imgNum,SVF,LVF,PathFlag,Deff,Time,nElements,converge,ds,df,dg"
+    assert rows[1].startswith("00000.jpg,0.653931,0.000000,1,2.247e+05,")
+    cmap = open(tmp_path / "CMAP.csv").read().splitlines()
+    assert cmap[0] == "X,Y,C" and len(cmap) == 1 + 128 * 128 and cmap[1].startswith("0,0,")
