@@ -10,7 +10,13 @@
 //
 //   deff2d [input.txt] [--device N] [--json results.json] [--field-bin prefix] [--batch-size B]
 //
+// --batch-size B (2-phase batch mode): images of equal size are solved B at a time in one stacked
+// context (deff_create_batch) -- each image still stops by its own convergence rule, the numbers are
+// those of the one-at-a-time run, but small images fill the GPU.  Default: as many images as bring
+// the stack to ~4 Mi cells (1 for images that large).
+//
 // This is host-side orchestration only; all arithmetic of the hot path happens behind the C ABI.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -82,17 +88,17 @@ static std::vector<unsigned int> grid_of(const Image &im, const Options &o, int 
     return g;
 }
 
-struct Session {                   // one solver context, re-created only when the mesh changes
+struct Session {                   // one solver context, re-created only when the mesh / batch size changes
     deff_ctx *ctx = nullptr;
-    int nx = 0, ny = 0, device = 0;
+    int nx = 0, ny = 0, nimg = 0, device = 0;
     ~Session() { deff_destroy(ctx); }
-    bool prepare(int nx_, int ny_)
+    bool prepare(int nx_, int ny_, int nimg_ = 1)
     {
-        if (ctx && nx == nx_ && ny == ny_) return true;
+        if (ctx && nx == nx_ && ny == ny_ && nimg == nimg_) return true;
         deff_destroy(ctx);
         ctx = nullptr;
-        CK(deff_create(device, nx_, ny_, &ctx));
-        nx = nx_; ny = ny_;
+        CK(deff_create_batch(device, nx_, ny_, nimg_, &ctx));
+        nx = nx_; ny = ny_; nimg = nimg_;
         return true;
     }
 };
@@ -155,6 +161,38 @@ static bool solve_2phase(Session &S, const Image &im, const Options &o, bool sin
     }
     row->seconds = ms_total / 1000.0;
     if (field) { field->resize((size_t)nx * ny); CK(deff_get_field(S.ctx, field->data())); }
+    return true;
+}
+
+// BatchSim over a group of equally sized images in ONE stacked context (cuh:1843-2054 per image).
+static bool solve_2phase_group(Session &S, const std::vector<Image> &ims, const Options &o, Row *rows,
+                               std::vector<double> *fields)
+{
+    const int B = (int)ims.size();
+    const int nx = ims[0].W * o.MeshIncreaseX, ny = ims[0].H * o.MeshIncreaseY;
+    if (!S.prepare(nx, ny, B)) return false;
+    std::vector<uint8_t> stack((size_t)B * ims[0].W * ims[0].H);
+    for (int k = 0; k < B; ++k) {
+        std::memcpy(&stack[(size_t)k * ims[0].W * ims[0].H], ims[k].pix.data(), ims[k].pix.size());
+        rows[k].nElements = nx * ny;
+        rows[k].porosity = porosity_of(ims[k]);
+        std::vector<unsigned int> grid = grid_of(ims[k], o, 150);
+        CK(deff_flood_fill(grid.data(), nx, ny, &rows[k].path));
+    }
+    CK(deff_set_image(S.ctx, stack.data(), ims[0].W, ims[0].H, o.MeshIncreaseX, o.MeshIncreaseY));
+    CK(deff_init_linear(S.ctx, o.CLeft, o.CRight));
+    CK(deff_assemble_2phase(S.ctx, o.DCsolid, o.DCfluid, o.CLeft, o.CRight));
+    std::vector<deff_result> res(B);
+    CK(deff_solve_batch(S.ctx, 2.0 / 3.0, o.ConvergeCriteria, o.MAX_ITER, 10000, res.data(), nullptr, nullptr));
+    for (int k = 0; k < B; ++k) {
+        rows[k].deff = res[k].deff_raw / o.DCfluid;                  // cuh:2017
+        rows[k].conv = res[k].conv;
+        rows[k].iters = (long)res[k].iters;
+        rows[k].stages.push_back((long)res[k].iters);
+        rows[k].seconds = res[k].loop_ms / 1000.0 / B;               // the group shares one loop
+        if (o.verbose == 1) std::printf("Number%dDCF = %g, Deff %g\n", k, o.DCfluid, rows[k].deff);
+    }
+    if (fields) { fields->resize((size_t)B * nx * ny); CK(deff_get_field(S.ctx, fields->data())); }
     return true;
 }
 
@@ -267,14 +305,15 @@ static void write_json(const std::string &path, const Options &o, const std::vec
 int main(int argc, char **argv)
 {
     std::string input = "input.txt", json, field_prefix;            // fixed name in the reference, Deff2D.cu:13
-    int device = 0;
+    int device = 0, batch_size = 0;
     for (int a = 1; a < argc; ++a) {
         const std::string s = argv[a];
         if (s == "--device" && a + 1 < argc) device = std::atoi(argv[++a]);
         else if (s == "--json" && a + 1 < argc) json = argv[++a];
         else if (s == "--field-bin" && a + 1 < argc) field_prefix = argv[++a];
+        else if (s == "--batch-size" && a + 1 < argc) batch_size = std::atoi(argv[++a]);
         else if (s == "-h" || s == "--help") {
-            std::printf("usage: deff2d [input.txt] [--device N] [--json results.json] [--field-bin prefix]\n");
+            std::printf("usage: deff2d [input.txt] [--device N] [--json results.json] [--field-bin prefix] [--batch-size B]\n");
             return 0;
         } else if (!s.empty() && s[0] != '-') input = s;
         else { std::fprintf(stderr, "deff2d: unknown argument %s\n", s.c_str()); return 2; }
@@ -289,32 +328,66 @@ int main(int argc, char **argv)
     const int count = o.BatchFlag ? o.NumImg : 1;
     std::vector<Row> rows;
     const bool want_field = o.printCmap == 1 || !field_prefix.empty();
-    for (int k = 0; k < count; ++k) {
+    auto emit_field = [&](int k, const double *x, int nx, int ny) {
+        if (o.printCmap == 1) {
+            char cm[32];
+            std::snprintf(cm, sizeof cm, "CMAP_%05d.csv", k);        // batch naming, cuh:2387
+            write_cmap(o.BatchFlag ? std::string(cm) : o.CMapName, std::vector<double>(x, x + (size_t)nx * ny), nx, ny);
+        }
+        if (!field_prefix.empty()) {
+            char fn[512];
+            std::snprintf(fn, sizeof fn, "%s_%05d_%dx%d.f64", field_prefix.c_str(), k, nx, ny);
+            if (FILE *f = std::fopen(fn, "wb")) { std::fwrite(x, sizeof(double), (size_t)nx * ny, f); std::fclose(f); }
+        }
+    };
+    for (int k = 0; k < count;) {
         char numbered[32];
         std::snprintf(numbered, sizeof numbered, "%05d.jpg", k);     // cuh:1876
         const std::string name = o.BatchFlag ? std::string(numbered) : o.inputFilename;
         Image im;
         if (!load_image(name, &im)) return 1;
+        if (o.verbose == 1) std::printf("Width = %d Height = %d Channel = %d\n", im.W, im.H, im.nChannels);
+        const int nx = im.W * o.MeshIncreaseX, ny = im.H * o.MeshIncreaseY;
+        // 2-phase batch mode: gather following images of the same size into one stacked context
+        int want = 1;
+        if (o.BatchFlag && o.nPhase == 2) {
+            want = batch_size > 0 ? batch_size : (int)std::max<long long>(1, (4ll << 20) / ((long long)nx * ny));
+            if (want > count - k) want = count - k;
+        }
+        if (want > 1) {
+            std::vector<Image> group;
+            group.push_back(std::move(im));
+            while ((int)group.size() < want) {
+                std::snprintf(numbered, sizeof numbered, "%05d.jpg", k + (int)group.size());
+                Image nxt;
+                if (!load_image(numbered, &nxt)) return 1;
+                if (nxt.W != group[0].W || nxt.H != group[0].H) break;       // different size: starts the next group
+                group.push_back(std::move(nxt));
+            }
+            std::vector<Row> grows(group.size());
+            for (size_t q = 0; q < group.size(); ++q) {
+                std::snprintf(numbered, sizeof numbered, "%05d.jpg", k + (int)q);
+                grows[q].name = numbered;
+            }
+            std::vector<double> fields;
+            if (!solve_2phase_group(S, group, o, grows.data(), want_field ? &fields : nullptr)) return 1;
+            for (size_t q = 0; q < group.size(); ++q) {
+                if (want_field) emit_field(k + (int)q, fields.data() + q * (size_t)nx * ny, nx, ny);
+                rows.push_back(grows[q]);
+            }
+            k += (int)group.size();
+            continue;
+        }
         Row row;
         row.name = name;
-        if (o.verbose == 1) std::printf("Width = %d Height = %d Channel = %d\n", im.W, im.H, im.nChannels);
         std::vector<double> field;
         const bool ok = (o.nPhase == 2) ? solve_2phase(S, im, o, !o.BatchFlag, &row, want_field ? &field : nullptr)
                                         : solve_3phase(S, im, o, &row, want_field ? &field : nullptr);
         if (!ok) return 1;
         if (o.verbose == 1 && o.nPhase == 2) std::printf("Porosity = %g\n", row.porosity);
-        const int nx = im.W * o.MeshIncreaseX, ny = im.H * o.MeshIncreaseY;
-        if (o.printCmap == 1) {
-            char cm[32];
-            std::snprintf(cm, sizeof cm, "CMAP_%05d.csv", k);        // batch naming, cuh:2387
-            write_cmap(o.BatchFlag ? std::string(cm) : o.CMapName, field, nx, ny);
-        }
-        if (!field_prefix.empty()) {
-            char fn[512];
-            std::snprintf(fn, sizeof fn, "%s_%05d_%dx%d.f64", field_prefix.c_str(), k, nx, ny);
-            if (FILE *f = std::fopen(fn, "wb")) { std::fwrite(field.data(), sizeof(double), field.size(), f); std::fclose(f); }
-        }
+        if (want_field) emit_field(k, field.data(), nx, ny);
         rows.push_back(row);
+        ++k;
     }
     write_csv(o, rows);                                              // after ALL images, like the reference (cuh:2051)
     if (!json.empty()) write_json(json, o, rows);

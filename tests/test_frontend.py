@@ -134,3 +134,36 @@ def test_driver_3phase_as_shipped(built, tmp_path, recorded):
     assert rows[1].startswith("00000.jpg,0.653931,0.000000,1,2.247e+05,")
     cmap = open(tmp_path / "CMAP.csv").read().splitlines()
     assert cmap[0] == "X,Y,C" and len(cmap) == 1 + 128 * 128 and cmap[1].startswith("0,0,")
+
+
+@pytest.mark.gpu
+def test_driver_batch_groups_images(built, tmp_path, oracle):
+    """RunBatch over 7 images of 96x64 solved in stacked groups of 3: every row equals the oracle's
+    one-image result, whatever the grouping."""
+    from PIL import Image
+    rng = np.random.default_rng(123)
+    pixs = []
+    for k in range(7):
+        a = np.where(rng.random((64, 96)) < 0.35 + 0.05 * k, 0, 255).astype(np.uint8)
+        Image.fromarray(a).save(tmp_path / f"{k:05d}.jpg", quality=95)
+    import effectivediffusivityfvm_amd as pkg
+    for k in range(7):
+        pixs.append(pkg.load_jpeg_gray(tmp_path / f"{k:05d}.jpg"))
+    _write_input(tmp_path / "input.txt", Phases=2, Ds="1e-2", Df=1, MeshAmpX=1, MeshAmpY=1, CR=1, CL=0,
+                 OutputName="out.csv", printCMap=0, Convergence="1e-4", MaxIter="2e5", Verbose=0, RunBatch=1,
+                 NumImages=7)
+    results = {}
+    for bs in (3, 1):
+        r = subprocess.run([EXE, "input.txt", "--json", f"res{bs}.json", "--batch-size", str(bs)], cwd=tmp_path,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr + r.stdout
+        results[bs] = json.load(open(tmp_path / f"res{bs}.json"))["results"]
+    for k in range(7):
+        D = oracle.fill_D_2phase(pixs[k], 1.0, 1e-2)
+        A, b = oracle.discretize(D, 0.0, 1.0)
+        it, deff, conv, _, _, _ = oracle.jacobi(A, b, oracle.linear_guess(96, 64, 0.0, 1.0), D, 0.0, 1.0, 1e-4, 200000)
+        for bs in (3, 1):
+            res = results[bs][k]
+            assert res["image"] == f"{k:05d}.jpg"
+            assert (res["iterations"], res["Deff"], res["converge"]) == (it, deff, conv), (bs, k)
+            assert res["PathFlag"] == int(oracle.floodfill((pixs[k] > 150).astype(np.uint32))[1])
