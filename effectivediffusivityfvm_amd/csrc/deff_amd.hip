@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -25,8 +26,10 @@
 #include "flood_fill.hpp"
 #include "fvm_row.hpp"
 #include "kernels_setup.hpp"
+#include "kernels_dict.hpp"
 #include "kernels_sweep.hpp"
 #include "kernels_tb.hpp"
+#include "lut_layout.hpp"
 
 using namespace deff;
 
@@ -87,13 +90,16 @@ struct deff_ctx {
     bool have_explicit = false;
     double c0_omega = NAN;          // omega the c0 plane was built for
 
-    // matrix-free system
-    uint8_t *code = nullptr;
-    double *lut = nullptr;          // device copy of the tables
-    double *lut_tb = nullptr;       // device copy in the 16-class layout of kernels_tb.hpp
-    std::vector<double> lut_a0;     // host: A0 plane per class/code (c0 = w/A0 on demand)
-    std::vector<double> lut_host;   // host: full tables
+    // matrix-free system: one 16-bit code per cell + the dictionary of distinct rows (lut_layout.hpp)
+    uint16_t *code = nullptr;
+    double *lut = nullptr;          // device tables [LUT_PLANES][LUT_PLANE_STRIDE]
+    std::vector<double> lut_rows;   // host: rows [nrows][6] = A0, aW, aE, aS, aN, b (row 0 = zeros)
+    int lut_nrows = 0;
+    bool lut_allb = false;          // some row away from the walls has b != 0 (harvested dictionaries only)
+    bool lut_guard = false;         // some c0 = w/A0 is not finite: the reference's non-zero link test matters
     bool have_matfree = false;
+    bool dict_tried = false;        // a dictionary was already looked for in the current explicit system
+    int dict_enabled = 1;
     double lut_omega = NAN;
     double Ds = 0, Df = 0;          // phase diffusivities of the native 2-phase system
 
@@ -266,7 +272,7 @@ extern "C" int deff_destroy(deff_ctx *c)
     if (!c) return DEFF_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->pix, c->a0, c->c0, c->aW, c->aE, c->aS, c->aN, c->b, c->code, c->lut, c->lut_tb,
+    void *bufs[] = {c->pix, c->a0, c->c0, c->aW, c->aE, c->aS, c->aN, c->b, c->code, c->lut,
                     c->Dl, c->Dr, c->mf, c->x[0], c->x[1], c->scratch, c->active};
     for (void *p : bufs) if (p) (void)hipFree(p);
     if (c->mf_host) (void)hipHostFree(c->mf_host);
@@ -317,7 +323,13 @@ static int resolve_kernel(const deff_ctx *c, int *k)
     int want = c->kernel;
     if (want == DEFF_KERNEL_AUTO) want = c->have_matfree ? DEFF_KERNEL_MATFREE_TB : DEFF_KERNEL_EXPLICIT;
     if (want == DEFF_KERNEL_MATFREE || want == DEFF_KERNEL_MATFREE_TB) {
-        if (!c->have_matfree) return fail(DEFF_ESTATE, "matrix-free kernels need deff_assemble_2phase()");
+        if (!c->have_matfree) {
+            // an explicit system without a usable row dictionary stays on the explicit kernels
+            if (!c->have_explicit) return fail(DEFF_ESTATE, "no system assembled");
+            want = (c->nx & 1) ? DEFF_KERNEL_SCALAR : DEFF_KERNEL_EXPLICIT;
+            *k = want;
+            return DEFF_OK;
+        }
         // the temporally blocked kernel needs 16-B aligned strips (even nx) and a few rows to stream
         if (want == DEFF_KERNEL_MATFREE_TB && ((c->nx & 1) || c->ny < 8)) want = DEFF_KERNEL_MATFREE;
     } else {
@@ -345,6 +357,7 @@ extern "C" int deff_set_tuning(deff_ctx *c, const char *key, int value)
     else if (!strcmp(key, "serpentine")) c->serpentine = value ? 1 : 0;
     else if (!strcmp(key, "tb_T")) c->tb_T = value;
     else if (!strcmp(key, "tb_LY")) c->tb_LY = value;
+    else if (!strcmp(key, "dict")) c->dict_enabled = value ? 1 : 0;
     else if (!strcmp(key, "tb_xmajor")) c->tb_xmajor = value ? 1 : 0;
     else if (!strcmp(key, "tb_wg")) c->tb_wg = (value + 7) / 8 * 8;
     else return fail(DEFF_EINVAL, "unknown tuning key '%s'", key);
@@ -404,48 +417,46 @@ extern "C" int deff_get_image(deff_ctx *c, uint8_t *pix)
 
 // --------------------------------------------------------- assembly -------
 
-// Tables for the matrix-free kernels: for every position class and phase code,
-// the matrix row fvm_row() would produce.  Built on the host with the same
-// routine the device assembly uses, so they hold the very same doubles.
+// Row dictionary of the native 2-phase system, enumerated a priori: for every position class and
+// every own/W/E/S/N phase pattern the matrix row fvm_row() produces -- built on the host with the
+// same routine the device assembly uses, so it holds the very same doubles.  Row 0 = zeros.
 static void build_lut_rows(deff_ctx *c, double Ds, double Df, double CL, double CR)
 {
-    c->lut_host.assign(LUT_DOUBLES, 0.0);
-    c->lut_a0.assign(LUT_PLANE_STRIDE, 0.0);
+    c->lut_nrows = LUT_NATIVE_ROWS;
+    c->lut_rows.assign((size_t)c->lut_nrows * 6, 0.0);
     for (int ycls = 0; ycls < 3; ++ycls)
         for (int xcls = 0; xcls < 3; ++xcls)
-            for (int code = 0; code < LUT_CODES; ++code) {
+            for (int code = 0; code < 32; ++code) {
                 auto D = [&](int bit) { return ((code >> bit) & 1) ? Ds : Df; };
-                FvmRow r = fvm_row(D(0), D(1), D(2), D(3), D(4), xcls, ycls, c->dx, c->dy, CL, CR);
-                const int idx = (ycls * 3 + xcls) * LUT_CODES + code;
-                c->lut_a0[idx] = r.a0;
-                c->lut_host[1 * LUT_PLANE_STRIDE + idx] = r.aW;
-                c->lut_host[2 * LUT_PLANE_STRIDE + idx] = r.aE;
-                c->lut_host[3 * LUT_PLANE_STRIDE + idx] = r.aS;
-                c->lut_host[4 * LUT_PLANE_STRIDE + idx] = r.aN;
-                c->lut_host[5 * LUT_PLANE_STRIDE + idx] = r.b;
+                const FvmRow r = fvm_row(D(0), D(1), D(2), D(3), D(4), xcls, ycls, c->dx, c->dy, CL, CR);
+                double *row = &c->lut_rows[(size_t)(1 + (ycls * 3 + xcls) * 32 + code) * 6];
+                row[0] = r.a0; row[1] = r.aW; row[2] = r.aE; row[3] = r.aS; row[4] = r.aN; row[5] = r.b;
             }
+    c->lut_allb = false;
     c->lut_omega = NAN;
 }
 
+// Device tables for a given omega: plane 0 holds c0 = omega / A0 (the reference divides w by
+// A[p*5+0] first, cuh:89), the other planes the links and b.
 static int upload_lut(deff_ctx *c, double omega)
 {
     if (c->lut_omega == omega) return DEFF_OK;
-    for (int i = 0; i < LUT_PLANE_STRIDE; ++i) c->lut_host[i] = omega / c->lut_a0[i];
+    std::vector<double> t(LUT_DOUBLES, 0.0);
+    bool guard = false;
+    for (int k = 1; k < c->lut_nrows; ++k) {
+        const double *row = &c->lut_rows[(size_t)k * 6];
+        const double c0 = omega / row[0];
+        if (!std::isfinite(c0)) guard = true;
+        t[k] = c0;
+        for (int pl = 1; pl < LUT_PLANES; ++pl) t[(size_t)pl * LUT_PLANE_STRIDE + k] = row[pl];
+    }
     TRY(dev_alloc(&c->lut, (size_t)LUT_DOUBLES));
-    HIP_TRY(hipMemcpyAsync(c->lut, c->lut_host.data(), sizeof(double) * LUT_DOUBLES, hipMemcpyHostToDevice,
-                           c->stream));
-    // 16-class layout for the temporally blocked kernel: class 3 (outside the mesh) stays zero
-    std::vector<double> tb(TB_LUT_DOUBLES, 0.0);
-    for (int pl = 0; pl < LUT_PLANES; ++pl)
-        for (int y = 0; y < 3; ++y)
-            for (int xq = 0; xq < 3; ++xq)
-                for (int code = 0; code < LUT_CODES; ++code)
-                    tb[pl * TB_PLANE_STRIDE + (y * 4 + xq) * LUT_CODES + code] =
-                        c->lut_host[pl * LUT_PLANE_STRIDE + (y * 3 + xq) * LUT_CODES + code];
-    TRY(dev_alloc(&c->lut_tb, (size_t)TB_LUT_DOUBLES));
-    HIP_TRY(hipMemcpyAsync(c->lut_tb, tb.data(), sizeof(double) * TB_LUT_DOUBLES, hipMemcpyHostToDevice,
-                           c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));   // host staging may be rewritten by the next call
+    HIP_TRY(hipMemcpyAsync(c->lut, t.data(), sizeof(double) * LUT_DOUBLES, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // `t` goes out of scope
+    // With every c0 finite the field stays finite, a zero link then contributes exactly +-0 and the
+    // reference's `A != 0` test (cuh:77) cannot change a bit; otherwise (a phase that cannot
+    // diffuse made a singular row) the guarded kernels keep its skip semantics.
+    c->lut_guard = guard;
     c->lut_omega = omega;
     return DEFF_OK;
 }
@@ -464,6 +475,7 @@ extern "C" int deff_assemble_2phase(deff_ctx *c, double Ds, double Df, double CL
 
     // matrix-free form: 1 byte per cell + lookup tables
     TRY(dev_alloc(&c->code, c->n));
+    c->dict_tried = false;
     hipLaunchKernelGGL(k_phase_codes, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->W, c->ampX,
                        c->ampY, c->nx, c->ny, c->rows, c->dom_lo, c->mesh_ny, c->code);
     HIP_TRY(hipGetLastError());
@@ -524,7 +536,7 @@ extern "C" int deff_assemble_3phase(deff_ctx *c, double Ds, double Df, double Dg
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));        // Grid may be freed by the caller
     c->have_explicit = true; c->c0_omega = NAN; c->have_walls = true;
-    c->have_matfree = false;
+    c->have_matfree = false; c->dict_tried = false;
     return DEFF_OK;
 }
 
@@ -583,7 +595,7 @@ extern "C" int deff_assemble_from_D(deff_ctx *c, const double *D, const unsigned
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_explicit = true; c->c0_omega = NAN; c->have_walls = true;
-    c->have_matfree = false;
+    c->have_matfree = false; c->dict_tried = false;
     return DEFF_OK;
 }
 
@@ -620,7 +632,7 @@ extern "C" int deff_set_system(deff_ctx *c, const double *A, const double *b, co
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_explicit = true; c->c0_omega = NAN;
-    c->have_matfree = false;
+    c->have_matfree = false; c->dict_tried = false;
     return DEFF_OK;
 }
 
@@ -644,18 +656,15 @@ extern "C" int deff_get_system(deff_ctx *c, double *A, double *b)
         return DEFF_OK;
     }
     if (c->have_matfree) {
-        // expand codes through the tables (what the matrix-free kernel "sees")
-        std::vector<uint8_t> code(c->n);
-        HIP_TRY(hipMemcpyAsync(code.data(), c->code, c->n, hipMemcpyDeviceToHost, c->stream));
+        // expand the codes through the row dictionary (what the matrix-free kernels "see")
+        std::vector<uint16_t> code(c->n);
+        HIP_TRY(hipMemcpyAsync(code.data(), c->code, sizeof(uint16_t) * c->n, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        for (int i = 0; i < c->rows; ++i)
-            for (int j = 0; j < c->nx; ++j) {
-                const size_t p = (size_t)i * c->nx + j;
-                const int idx = (pos_class(i % c->ny, c->ny) * 3 + pos_class(j, c->nx)) * LUT_CODES + ((code[p] >> 3) & 31);
-                A[p * 5 + 0] = c->lut_a0[idx];
-                for (int k = 1; k < 5; ++k) A[p * 5 + k] = c->lut_host[k * LUT_PLANE_STRIDE + idx];
-                b[p] = c->lut_host[5 * LUT_PLANE_STRIDE + idx];
-            }
+        for (size_t p = 0; p < c->n; ++p) {
+            const double *row = &c->lut_rows[(size_t)(code[p] >> 3) * 6];
+            for (int k = 0; k < 5; ++k) A[p * 5 + k] = row[k];
+            b[p] = row[5];
+        }
         return DEFF_OK;
     }
     return fail(DEFF_ESTATE, "no system assembled");
@@ -741,11 +750,6 @@ struct SweepPlan {
     int T = 0, CPL = 2, LY = 0, tcpi = 0, ntx = 0, tgx = 0, tgy = 0, tblocks = 0;
     int T_override = 0;                                   // slab mode plans a T = 1 pass for remainders
     bool guard = false;
-    // the reference's non-zero link test matters only when a phase cannot diffuse
-    static bool guard_probe(const deff_ctx *c)
-    {
-        return !(c->Ds > 0 && c->Df > 0 && std::isfinite(c->Ds) && std::isfinite(c->Df));
-    }
 };
 
 // Workgroups of the temporally blocked kernel that are resident at once on this device.
@@ -799,17 +803,96 @@ static void tile_grid(const deff_ctx *c, int cols_per_block, int rows, SweepPlan
     pl->blocks = (int)(((total + 7u) / 8u) * 8u);      // see xcd_tile()
 }
 
+static int default_tb_T(const deff_ctx *c)
+{
+    if (c->n < ((size_t)1 << 22)) return 4;
+    return (c->nimg == 1 && !c->slab && c->n >= ((size_t)1 << 24)) ? 8 : 6;
+}
+
+// Harvest the row dictionary of the explicit system (kernels_dict.hpp).  On success the context
+// also has a matrix-free form (codes + tables); when the system has too many distinct rows it
+// simply keeps running on the explicit kernels.
+static int try_dict(deff_ctx *c)
+{
+    c->dict_tried = true;
+    if (!c->have_explicit || (c->nx & 1)) return DEFF_OK;
+    const size_t S = DICT_SLOTS;
+    const size_t bytes = S * (8 + 4 + 8) + 16 + S * 2 + (size_t)LUT_MAX_ROWS * (8 + 48);
+    TRY(ensure_scratch(c, bytes));
+    char *base = (char *)c->scratch;
+    DictTable t;
+    t.key = (unsigned long long *)base;
+    t.rep = (unsigned long long *)(base + S * 8);
+    t.count = (unsigned int *)(base + S * 16);
+    t.flags = (unsigned int *)(base + S * 20);
+    uint16_t *d_slot2code = (uint16_t *)(base + S * 20 + 16);
+    unsigned long long *d_cells = (unsigned long long *)(base + S * 22 + 16);
+    double *d_rows = (double *)(base + S * 22 + 16 + (size_t)LUT_MAX_ROWS * 8);
+    HIP_TRY(hipMemsetAsync(base, 0, S * 20 + 16, c->stream));
+    const CoefSoA planes = soa_of(c);
+    hipLaunchKernelGGL(k_dict_insert, dim3(grid_for(c->n, 4096)), dim3(256), 0, c->stream, planes, c->n, t);
+    HIP_TRY(hipGetLastError());
+    std::vector<unsigned long long> key(S), rp(S);
+    std::vector<unsigned int> cnt(S);
+    unsigned int flags[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(key.data(), t.key, S * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(rp.data(), t.rep, S * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(cnt.data(), t.count, S * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(flags, t.flags, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (flags[0]) return DEFF_OK;                                 // table overflow: far too many rows
+    struct Ent { unsigned int count; unsigned long long cell; unsigned slot; };
+    std::vector<Ent> ents;
+    for (unsigned sl = 0; sl < S; ++sl)
+        if (key[sl]) ents.push_back({cnt[sl], rp[sl] - 1, sl});
+    if (ents.empty() || (int)ents.size() + 1 > LUT_MAX_ROWS) return DEFF_OK;
+    // most populous rows first: the 32 commonest rows then share one conflict-free LDS bank row
+    std::sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) {
+        return a.count != b.count ? a.count > b.count : a.cell < b.cell;
+    });
+    std::vector<uint16_t> slot2code(S, 0xFFFFu);
+    std::vector<unsigned long long> cells(ents.size());
+    for (size_t k = 0; k < ents.size(); ++k) {
+        slot2code[ents[k].slot] = (uint16_t)((k + 1) * 8);
+        cells[k] = ents[k].cell;
+    }
+    HIP_TRY(hipMemcpyAsync(d_slot2code, slot2code.data(), S * 2, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_cells, cells.data(), cells.size() * 8, hipMemcpyHostToDevice, c->stream));
+    const int nrows = (int)ents.size();
+    hipLaunchKernelGGL(k_dict_gather, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, planes, d_cells, nrows, d_rows);
+    TRY(dev_alloc(&c->code, c->n));
+    hipLaunchKernelGGL(k_dict_encode, dim3(grid_for(c->n, 4096)), dim3(256), 0, c->stream, planes, c->n, c->nx, t,
+                       d_slot2code, c->code);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> rows((size_t)nrows * 6);
+    HIP_TRY(hipMemcpyAsync(rows.data(), d_rows, rows.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(flags, t.flags, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (flags[1]) return DEFF_OK;                                 // hash collision (astronomically unlikely): stay explicit
+    c->lut_nrows = nrows + 1;
+    c->lut_rows.assign((size_t)c->lut_nrows * 6, 0.0);
+    memcpy(&c->lut_rows[6], rows.data(), rows.size() * 8);
+    c->lut_allb = flags[2] != 0;
+    c->lut_omega = NAN;
+    c->have_matfree = true;
+    return DEFF_OK;
+}
+
 static int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
 {
     if (!c->have_field) return fail(DEFF_ESTATE, "no field: call deff_init_linear() or deff_set_field()");
+    // an explicit system (host-assembled, 3-phase, ImpSolid) with few distinct rows also runs matrix-free
+    if (!c->have_matfree && c->have_explicit && !c->dict_tried && c->dict_enabled &&
+        (c->kernel == DEFF_KERNEL_AUTO || c->kernel == DEFF_KERNEL_MATFREE || c->kernel == DEFF_KERNEL_MATFREE_TB))
+        TRY(try_dict(c));
     TRY(resolve_kernel(c, &pl->kernel));
     pl->omw = 1.0 - omega;                              // cuh:89 evaluates (1.0 - w) in double
     if (pl->kernel == DEFF_KERNEL_MATFREE || pl->kernel == DEFF_KERNEL_MATFREE_TB) {
         TRY(upload_lut(c, omega));
         if (pl->kernel == DEFF_KERNEL_MATFREE_TB) {
-            // sweeps per pass: 6 once the stack is big enough to fill the chip (measured at 4096^2:
-            // T=4 919, T=6 1005, T=8 1046 G cells*iter/s; 16 x 1024^2: 879 / 966 / 932), else 4
-            int T = pl->T_override ? pl->T_override : (c->tb_T ? c->tb_T : (c->n >= ((size_t)1 << 22) ? 6 : 4));
+            // sweeps per pass (measured, G cells*iter/s: 4096^2 T=4 926, T=6 1063, T=8 1106; stacks of
+            // 16 x 1024^2 peak at T=6; 1024^2 alone at T=4)
+            int T = pl->T_override ? pl->T_override : (c->tb_T ? c->tb_T : default_tb_T(c));
             T = T >= 8 ? 8 : T >= 6 ? 6 : T >= 4 ? 4 : T >= 2 ? 2 : 1;
             pl->T = T;
             pl->CPL = 2;
@@ -819,7 +902,7 @@ static int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             // pass takes rounds x (LY + 2T) row steps, where one round is as many block
             // tiles as are resident at once.  Pick the (rounds, LY) pair minimising that.
             int resident = c->tb_wg;
-            if (!resident) TRY(tb_resident_blocks(c, T, pl->CPL, SweepPlan::guard_probe(c), &resident));
+            if (!resident) TRY(tb_resident_blocks(c, T, pl->CPL, c->lut_guard, &resident));
             int LY = c->tb_LY;
             if (!LY) {
                 long best_cost = -1;
@@ -844,7 +927,7 @@ static int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             pl->tblocks = (int)(((total + 7u) / 8u) * 8u);
             if (pl->tblocks > resident) pl->tblocks = resident >= 8 ? resident / 8 * 8 : 8;
             // the reference's non-zero link test matters only when a phase cannot diffuse
-            pl->guard = SweepPlan::guard_probe(c);
+            pl->guard = c->lut_guard;
         }
         const int vec = (c->nx & 1) ? 1 : 2;
         tile_grid(c, 256 * vec, pick_R(c->rows_matfree, c->n >= ((size_t)1 << 21) ? 8 : 2), pl);
@@ -904,7 +987,7 @@ static inline void enqueue_sweep(deff_ctx *c, const SweepPlan &pl)
     default: {
 #define LAUNCH_MATFREE(V_, R_)                                                                               \
     hipLaunchKernelGGL((k_sweep_matfree<V_, R_>), dim3(pl.blocks), dim3(256), 0, c->stream, c->lut, c->code, \
-                       xin, xout, c->nx, c->ny, c->rows, pl.cpi, mask, pl.gx, pl.gy, flip, pl.omw)
+                       xin, xout, c->nx, c->ny, c->rows, pl.cpi, mask, pl.gx, pl.gy, flip, c->lut_nrows, pl.omw)
         if (c->nx & 1) {
             switch (pl.rows) {
             case 1: LAUNCH_MATFREE(1, 1); break;
@@ -935,9 +1018,10 @@ static inline void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl)
     const int flip = c->serpentine ? c->cur : 0;
     const uint8_t *mask = c->masked ? c->active : nullptr;
 #define LAUNCH_TB(T_, C_, G_)                                                                                  \
-    hipLaunchKernelGGL((k_sweep_matfree_tb<T_, C_, G_>), dim3(pl.tblocks), dim3(256), 0, c->stream, c->lut_tb, \
+    hipLaunchKernelGGL((k_sweep_matfree_tb<T_, C_, G_>), dim3(pl.tblocks), dim3(256), 0, c->stream, c->lut,    \
                        c->code, xin, xout, c->nx, c->mesh_ny, c->ny, c->dom_lo, c->own_lo, c->own_h, pl.tcpi, \
-                       mask, pl.LY, pl.ntx, pl.tgx, pl.tgy, flip, c->tb_xmajor, pl.omw)
+                       mask, pl.LY, pl.ntx, pl.tgx, pl.tgy, flip, c->tb_xmajor, c->lut_allb ? 1 : 0,         \
+                       c->lut_nrows, pl.omw)
     TB_DISPATCH(pl.T, pl.CPL, pl.guard, LAUNCH_TB);
 #undef LAUNCH_TB
     c->cur ^= 1;
@@ -1119,7 +1203,7 @@ extern "C" int deff_last_launches(const deff_ctx *c, int64_t *launches, int *swe
         int k = 0;
         *sweeps_per_pass = 1;
         if (resolve_kernel(c, &k) == DEFF_OK && k == DEFF_KERNEL_MATFREE_TB) {
-            int T = c->tb_T ? c->tb_T : (c->n >= ((size_t)1 << 22) ? 6 : 4);
+            int T = c->tb_T ? c->tb_T : default_tb_T(c);
             *sweeps_per_pass = T >= 8 ? 8 : T >= 6 ? 6 : T >= 4 ? 4 : 2;
         }
     }

@@ -103,23 +103,25 @@ __global__ void k_wall_D_from_D(const double *__restrict__ D, int nx, int rows,
     Dr[i] = D[(size_t)(i + 1) * nx - 1];
 }
 
-// Matrix-free phase code, one byte per cell, stored pre-scaled by 8 (= the byte
-// offset of the cell's entry inside a 32-entry x 8-B table group): bit3 own phase
-// (1 = solid, i.e. pixel >= 150), bit4 W, bit5 E, bit6 S (row+1), bit7 N (row-1)
-// neighbour phases.  Neighbours outside the mesh read the clamped cell; their bits are
-// never used because the lookup tables are selected by position class.
+// Matrix-free code, 16 bits per cell: the BYTE OFFSET (row index x 8) of the cell's matrix
+// row in the lookup tables (lut_layout.hpp).  Row 0 is the all-zero row (cells outside the
+// mesh); for the native 2-phase system row 1 + (ycls*3 + xcls)*32 + c5 holds the row of a cell
+// of position class (ycls, xcls) whose own / W / E / S(row+1) / N(row-1) phases are the bits
+// 0..4 of c5 (1 = solid, i.e. pixel >= 150).  Neighbours outside the mesh read the clamped
+// cell; their bits do not matter because the position class already removes those links.
+// dom_lo / mesh_ny: array row li of an image is mesh row li - dom_lo of a mesh_ny-row mesh
+// (dom_lo = 0, mesh_ny = ny except for a row slab, whose array is a window with halo rows).
 __global__ void k_phase_codes(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
                               int nx, int ny, int rows, int dom_lo, int mesh_ny,
-                              uint8_t *__restrict__ code)
+                              uint16_t *__restrict__ code)
 {
-    // dom_lo / mesh_ny: array row li of an image is mesh row li - dom_lo of a mesh_ny-row mesh
-    // (dom_lo = 0, mesh_ny = ny except for a row slab, whose array is a window with halo rows)
     const size_t n = (size_t)nx * rows;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
          p += (size_t)gridDim.x * blockDim.x) {
         int i = (int)(p / nx), j = (int)(p % nx);
         const int li = i % ny;                       // row inside its image's array
         const int gi = li - dom_lo;                  // mesh row
+        if (gi < 0 || gi >= mesh_ny) { code[p] = 0; continue; }
         int jw = j > 0 ? j - 1 : j, je = j < nx - 1 ? j + 1 : j;
         int is = (gi < mesh_ny - 1 && li < ny - 1) ? i + 1 : i;
         int in = (gi > 0 && li > 0) ? i - 1 : i;
@@ -128,7 +130,8 @@ __global__ void k_phase_codes(const uint8_t *__restrict__ pix, int W, int ampX, 
         c |= (cell_pixel(pix, W, ampX, ampY, ny, i, je) >= 150) ? 4u : 0u;
         c |= (cell_pixel(pix, W, ampX, ampY, ny, is, j) >= 150) ? 8u : 0u;
         c |= (cell_pixel(pix, W, ampX, ampY, ny, in, j) >= 150) ? 16u : 0u;
-        code[p] = (uint8_t)(c << 3);
+        const unsigned cls = (unsigned)(pos_class(gi, mesh_ny) * 3 + pos_class(j, nx));
+        code[p] = (uint16_t)((1u + cls * 32u + c) * 8u);
     }
 }
 

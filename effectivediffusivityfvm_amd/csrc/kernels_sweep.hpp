@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "lut_layout.hpp"
 
 namespace deff {
 
@@ -172,22 +173,27 @@ __global__ __launch_bounds__(256) void k_sweep_explicit(CoefConst c, const doubl
 
 // -------------------------------------------------------- matrix-free -----
 
-// Lookup tables: 6 planes (c0, aW, aE, aS, aN, b) x 9 position classes
-// (ypos*3 + xpos) x 32 phase codes.  A 32-entry x 8-B group is exactly one
-// 256-B LDS bank row, so ds_read_b64 with per-lane codes is conflict-free
-// whenever all lanes of a half-wave share the position class.
-constexpr int LUT_CODES = 32;
-constexpr int LUT_CLASSES = 9;
-constexpr int LUT_PLANES = 6;
-constexpr int LUT_PLANE_STRIDE = LUT_CLASSES * LUT_CODES;           // doubles
-constexpr int LUT_DOUBLES = LUT_PLANES * LUT_PLANE_STRIDE;          // 1728
-
-__device__ __forceinline__ double jacobi_cell_lut(const double *lut, int idx, double xc, double xw,
+// One cell from the row dictionary (lut_layout.hpp); `off` is the cell's code = byte offset of
+// its row inside a plane.
+__device__ __forceinline__ double jacobi_cell_lut(const double *lut, unsigned off, double xc, double xw,
                                                   double xe, double xs, double xn, double omw)
 {
-    return jacobi_cell(lut[idx], lut[idx + LUT_PLANE_STRIDE], lut[idx + 2 * LUT_PLANE_STRIDE],
-                       lut[idx + 3 * LUT_PLANE_STRIDE], lut[idx + 4 * LUT_PLANE_STRIDE],
-                       lut[idx + 5 * LUT_PLANE_STRIDE], xc, xw, xe, xs, xn, omw);
+    const char *base = reinterpret_cast<const char *>(lut) + off;
+    constexpr int PS = LUT_PLANE_STRIDE * 8;
+    return jacobi_cell(*reinterpret_cast<const double *>(base), *reinterpret_cast<const double *>(base + PS),
+                       *reinterpret_cast<const double *>(base + 2 * PS), *reinterpret_cast<const double *>(base + 3 * PS),
+                       *reinterpret_cast<const double *>(base + 4 * PS), *reinterpret_cast<const double *>(base + 5 * PS),
+                       xc, xw, xe, xs, xn, omw);
+}
+
+// Copy the first `nrows` rows of every plane of the dictionary into LDS (workgroup-wide).
+__device__ __forceinline__ void load_lut(double *lut, const double *__restrict__ lut_g, int nrows)
+{
+    for (int k = threadIdx.x; k < LUT_PLANES * nrows; k += 256) {
+        const int pl = k / nrows, r = k - pl * nrows;
+        lut[pl * LUT_PLANE_STRIDE + r] = lut_g[pl * LUT_PLANE_STRIDE + r];
+    }
+    __syncthreads();
 }
 
 // Tile -> XCD map for persistent grids: workgroup `wg` of `nwg` walks tiles
@@ -200,20 +206,19 @@ __device__ __forceinline__ void tile_coords(unsigned t, int gy, int &bx, int &by
 }
 
 // VEC = 2 needs nx even; VEC = 1 handles any nx.  Tile = 256*VEC columns x R
-// rows.  Persistent: the grid is a few workgroups per CU, each loads the tables
+// rows.  Position classes are folded into the codes at assembly, the kernel only looks rows up.  Persistent: the grid is a few workgroups per CU, each loads the tables
 // into LDS once and then walks its share of the tiles.
 template <int VEC, int R>
 __global__ __launch_bounds__(256) void k_sweep_matfree(const double *__restrict__ lut_g,
-                                                       const uint8_t *__restrict__ code,
+                                                       const uint16_t *__restrict__ code,
                                                        const double *__restrict__ x,
                                                        double *__restrict__ xnew, int nx, int ny,
                                                        int rows, int cpi,
                                                        const uint8_t *__restrict__ active, int gx,
-                                                       int gy, int flip, double omw)
+                                                       int gy, int flip, int nrows, double omw)
 {
     __shared__ double lut[LUT_DOUBLES];
-    for (int k = threadIdx.x; k < LUT_DOUBLES; k += 256) lut[k] = lut_g[k];
-    __syncthreads();
+    load_lut(lut, lut_g, nrows);
 
     const size_t n = (size_t)nx * rows;
     const unsigned total = (unsigned)gx * (unsigned)gy;
@@ -235,8 +240,6 @@ __global__ __launch_bounds__(256) void k_sweep_matfree(const double *__restrict_
         const size_t p0 = (size_t)r0 * nx + col;
 
         if constexpr (VEC == 2) {
-            const int xcls0 = (col == 0) ? 1 : 0;              // cell 0 can only be the first column
-            const int xcls1 = (col + 1 == nx - 1) ? 2 : 0;     // cell 1 can only be the last column
             const double2 zero = make_double2(0.0, 0.0);
             double2 xr[R + 2];
             double xw[R], xe[R];
@@ -252,16 +255,14 @@ __global__ __launch_bounds__(256) void k_sweep_matfree(const double *__restrict_
                 const size_t p = p0 + (size_t)q * nx;
                 xw[q] = (p >= 1 && p < n) ? x[p - 1] : 0.0;
                 xe[q] = (p + 2 < n) ? x[p + 2] : 0.0;
-                cc[q] = (p < n) ? *reinterpret_cast<const uint16_t *>(code + p) : 0u;
+                cc[q] = (p < n) ? *reinterpret_cast<const uint32_t *>(code + p) : 0u;   // two 16-bit codes
             }
 #pragma unroll
             for (int q = 0; q < R; ++q) {
                 const int r = r0 + q;
                 if (r >= rlim) break;
                 const size_t p = p0 + (size_t)q * nx;
-                const int ycls = (r == row_lo) ? 1 : (r == rlim - 1 ? 2 : 0);
-                const int i0 = (ycls * 3 + xcls0) * LUT_CODES + (int)((cc[q] >> 3) & 31u);
-                const int i1 = (ycls * 3 + xcls1) * LUT_CODES + (int)((cc[q] >> 11) & 31u);
+                const unsigned i0 = cc[q] & 0xFFFFu, i1 = cc[q] >> 16;
                 const double2 xm = xr[q], xc = xr[q + 1], xp = xr[q + 2];
                 double2 o;
                 o.x = jacobi_cell_lut(lut, i0, xc.x, xw[q], xc.y, xp.x, xm.x, omw);
@@ -269,7 +270,6 @@ __global__ __launch_bounds__(256) void k_sweep_matfree(const double *__restrict_
                 st2(xnew + p, o);
             }
         } else {
-            const int xcls = (col == 0) ? 1 : (col == nx - 1 ? 2 : 0);
             double xr[R + 2], xw[R], xe[R];
             unsigned cc[R];
             xr[0] = (p0 >= (size_t)nx) ? x[p0 - nx] : 0.0;
@@ -290,8 +290,7 @@ __global__ __launch_bounds__(256) void k_sweep_matfree(const double *__restrict_
                 const int r = r0 + q;
                 if (r >= rlim) break;
                 const size_t p = p0 + (size_t)q * nx;
-                const int ycls = (r == row_lo) ? 1 : (r == rlim - 1 ? 2 : 0);
-                const int i0 = (ycls * 3 + xcls) * LUT_CODES + (int)((cc[q] >> 3) & 31u);
+                const unsigned i0 = cc[q];
                 xnew[p] = jacobi_cell_lut(lut, i0, xr[q + 1], xw[q], xe[q], xr[q + 2], xr[q], omw);
             }
         }

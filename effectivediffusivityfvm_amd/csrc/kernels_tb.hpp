@@ -30,17 +30,6 @@
 
 namespace deff {
 
-// Tables for this kernel: 6 planes x 16 position classes (ycls*4 + xcls, class 3
-// = outside the mesh: all zeros, so such cells stay exactly 0) x 32 codes.
-// The plane stride is padded to 520 doubles on purpose: with a stride that is a
-// multiple of 512 B hipcc fuses the six per-cell lookups into ds_read2st64_b64,
-// which banks on 32 banks (2-way conflicts on a 32-entry x 8-B group, 16 LDS
-// cycles per instruction, measured as THE bottleneck of this kernel); with 4160 B
-// neither ds_read2 form can encode the offset, the lookups stay plain
-// ds_read_b64 (64 banks: a 256-B group is conflict-free, 2 cycles each).
-constexpr int TB_CLASSES = 16;
-constexpr int TB_PLANE_STRIDE = TB_CLASSES * LUT_CODES + 8;    // 520 doubles
-constexpr int TB_LUT_DOUBLES = LUT_PLANES * TB_PLANE_STRIDE;   // 3120 doubles = 24.4 KiB
 constexpr int TB_COLS = 128;                                   // columns per wave strip (2 per lane)
 
 // lane i <- lane i-1 (lane 0 <- 0.0)
@@ -60,8 +49,8 @@ __device__ __forceinline__ double from_lane_above(double v)
     return __hiloint2double(hi, lo);
 }
 
-// One cell.  `off` is the BYTE offset of the cell's entry in plane 0 (position
-// class group + pre-scaled phase code); the other planes sit at fixed strides.
+// One cell.  `off` is the cell's code: the BYTE offset of its row in plane 0 of the row
+// dictionary (lut_layout.hpp); the other planes sit at fixed strides.
 // GUARD = reference's non-zero test on every link (needed when a phase has zero
 // diffusivity: links are -0.0 and neighbours may hold NaN/Inf, cuh:77).  Without
 // it a zero link multiplies a finite value and adds +-0, which leaves sigma
@@ -73,7 +62,7 @@ __device__ __forceinline__ double tb_cell(const double *lut, unsigned off, doubl
                                           double xs, double xn, double omw)
 {
     const char *base = reinterpret_cast<const char *>(lut) + off;
-    constexpr int PS = TB_PLANE_STRIDE * 8;
+    constexpr int PS = LUT_PLANE_STRIDE * 8;
     const double c0 = *reinterpret_cast<const double *>(base);
     const double aW = *reinterpret_cast<const double *>(base + PS);
     const double aE = *reinterpret_cast<const double *>(base + 2 * PS);
@@ -94,11 +83,6 @@ __device__ __forceinline__ double tb_cell(const double *lut, unsigned off, doubl
     }
 }
 
-__device__ __forceinline__ int tb_ycls(int r, int ny)
-{
-    return (r < 0 || r >= ny) ? 3 : (r == 0 ? 1 : (r == ny - 1 ? 2 : 0));
-}
-
 // One strip x chunk: the whole row pipeline of a wave (2 cells per lane, 128 columns).
 // Geometry (array rows): the mesh of this image is rows [row_lo, row_lo+ny) -- rows outside it
 // are "outside the mesh" even if another image of a batch lives there, and row_lo is negative
@@ -110,7 +94,7 @@ __device__ __forceinline__ int tb_ycls(int r, int ny)
 // code is deliberately written with double2 values and named slots: an array-of-scalars
 // formulation of the same dataflow made hipcc hoist the lookups to 204 VGPRs.)
 template <int T, bool GUARD, bool WALL>
-__device__ __forceinline__ void tb_strip(const double *lut, const uint8_t *__restrict__ code,
+__device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__restrict__ code,
                                          const double *__restrict__ x, double *__restrict__ xnew, int nx,
                                          int ny, int row_lo, int own_hi, int tx, int ry0, int LY, int lane,
                                          double omw)
@@ -125,13 +109,10 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint8_t *__res
     const int ry1 = min(ry0 + LY, own_hi);
     const int r_begin = ry0 - T, r_end = ry1 + T;  // input rows [r_begin, r_end)
     const bool st_x = in_x && (col >= cx0) && (col < cx0 + WOUT);
-    // byte offsets of the two cells' x position class groups (3 = outside the mesh)
-    const unsigned xoff0 = (unsigned)(!in_x ? 3 : (col == 0 ? 1 : 0)) * (LUT_CODES * 8);
-    const unsigned xoff1 = (unsigned)(!in_x ? 3 : (col + 1 == nx - 1 ? 2 : 0)) * (LUT_CODES * 8);
     const double2 zero = make_double2(0.0, 0.0);
 
     double2 w[T][3];                               // w[t]: 3 newest rows of sweep t
-    unsigned cw[T + 1];                            // cw[t]: codes of row rr-t
+    unsigned cw[T + 1];                            // cw[t]: the two 16-bit codes of row rr-t
 #pragma unroll
     for (int t = 0; t < T; ++t) { w[t][0] = zero; w[t][1] = zero; w[t][2] = zero; }
 #pragma unroll
@@ -146,7 +127,7 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint8_t *__res
         const bool ok = in_x && rr >= row_lo && rr < row_hi && rr < r_end;
         const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col : 0);
         nx_x[k] = ok ? ld2(x + p) : zero;
-        nx_c[k] = ok ? (unsigned)*reinterpret_cast<const uint16_t *>(code + p) : 0u;
+        nx_c[k] = ok ? *reinterpret_cast<const uint32_t *>(code + p) : 0u;   // rows / lanes outside the mesh: zero row
     }
 
     for (int r = r_begin; r < r_end; r += 3) {
@@ -161,7 +142,7 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint8_t *__res
             const bool ok = in_x && rr >= row_lo && rr < row_hi && rr < r_end;
             const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col : 0);
             nx_x[k] = ok ? ld2(x + p) : zero;
-            nx_c[k] = ok ? (unsigned)*reinterpret_cast<const uint16_t *>(code + p) : 0u;
+            nx_c[k] = ok ? *reinterpret_cast<const uint32_t *>(code + p) : 0u;   // rows / lanes outside the mesh: zero row
         }
 #pragma unroll
         for (int ph = 0; ph < 3; ++ph) {
@@ -178,10 +159,7 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint8_t *__res
                 const double2 vN = w[t - 1][sN], vC = w[t - 1][sC], vS = w[t - 1][sS];
                 const double xw0 = from_lane_below(vC.y);
                 const double xe1 = from_lane_above(vC.x);
-                // byte offset = class group (multiple of 256) | pre-scaled code (< 256)
-                const unsigned ybase = (unsigned)tb_ycls(rt - row_lo, ny) * (4 * LUT_CODES * 8);
-                const unsigned o0 = (cw[t] & 0xF8u) | (ybase + xoff0);
-                const unsigned o1 = ((cw[t] >> 8) & 0xF8u) | (ybase + xoff1);
+                const unsigned o0 = cw[t] & 0xFFFFu, o1 = cw[t] >> 16;
                 double2 o;
                 o.x = tb_cell<GUARD, WALL>(lut, o0, vC.x, xw0, vC.y, vS.x, vN.x, omw);
                 o.y = tb_cell<GUARD, WALL>(lut, o1, vC.y, vC.x, xe1, vS.y, vN.y, omw);
@@ -210,19 +188,18 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint8_t *__res
 // own_lo = halo depth, own_h = rows owned by this rank.
 template <int T, int CPL, bool GUARD>
 __global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restrict__ lut_g,
-                                                          const uint8_t *__restrict__ code,
+                                                          const uint16_t *__restrict__ code,
                                                           const double *__restrict__ x,
                                                           double *__restrict__ xnew, int nx, int ny,
                                                           int img_stride, int dom_lo, int own_lo,
                                                           int own_h, int cpi,
                                                           const uint8_t *__restrict__ active,
                                                           int LY, int ntx, int nbt, int gy, int flip,
-                                                          int xmajor, double omw)
+                                                          int xmajor, int allb, int nrows, double omw)
 {
     static_assert(T >= 1 && T <= 8 && CPL == 2, "unsupported T / cells per lane");
-    __shared__ double lut[TB_LUT_DOUBLES];
-    for (int k = threadIdx.x; k < TB_LUT_DOUBLES; k += 256) lut[k] = lut_g[k];
-    __syncthreads();
+    __shared__ double lut[LUT_DOUBLES];
+    load_lut(lut, lut_g, nrows);
 
     const int lane = threadIdx.x & 63;
     // readfirstlane makes the wave index (and everything derived from it: strip, chunk, row
@@ -249,7 +226,9 @@ __global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restri
         const int own0 = own_lo + img * img_stride;
         const int ry0 = own0 + (bty - img * cpi) * LY;
 
-        if (tx == 0 || tx == ntx - 1)
+        // b is read only where it can be non-zero: strips holding a wall column, or everywhere for a
+        // harvested dictionary whose right-hand side is not confined to the walls
+        if (allb || tx == 0 || tx == ntx - 1)
             tb_strip<T, GUARD, true>(lut, code, x, xnew, nx, ny, row_lo, own0 + own_h, tx, ry0, LY, lane, omw);
         else
             tb_strip<T, GUARD, false>(lut, code, x, xnew, nx, ny, row_lo, own0 + own_h, tx, ry0, LY, lane, omw);

@@ -193,6 +193,7 @@ def test_img00000_3phase_as_shipped(pkg, oracle, recorded, img00000):
         r = batch.solve_image_3phase(s, img00000, o["Ds"], o["Df"], o["Dg"], o["CL"], o["CR"], o["tol"],
                                      o["max_iter"])
         field = s.get_field()
+        assert s.kernel_in_use() == "matfree_tb"        # ImpSolid rows harvested into a dictionary
     assert r["stage_sweeps"] == rec["stage_sweeps"]
     assert abs(r["deff"] - rec["deff"]) <= DEFF_TOL * rec["deff"]
     assert r["deff"] == rec["deff"] and r["conv"] == rec["conv"]
@@ -454,14 +455,50 @@ def test_host_assembled_system_drop_in(pkg, oracle):
     A, b = oracle.discretize(D, 0.0, 1.0)
     x0 = oracle.linear_guess(nx, ny, 0.0, 1.0)
     it, deff, conv, x, MFL, MFR = oracle.jacobi(A, b, x0, D, 0.0, 1.0, 1e-4, 40000, check_every=1000)
-    for kernel in ("explicit", "scalar"):
+    for kernel in ("explicit", "scalar", "auto"):
         with pkg.Solver(nx, ny, kernel=kernel) as s:
             s.set_system(A, b, D, 0.0, 1.0)
             s.set_field(x0)
             r = s.solve(1e-4, 40000, check_every=1000)
+            # "auto": the rows of a piecewise-constant system are few, so the library harvests their
+            # dictionary and runs the host-assembled system on the temporally blocked matrix-free kernel
+            assert s.kernel_in_use() == ("matfree_tb" if kernel == "auto" else kernel)
             assert r.iters == it and r.deff_raw == deff and r.conv == conv
             assert_field(s.get_field(), x)
             assert np.array_equal(r.MFL, MFL) and np.array_equal(r.MFR, MFR)
+            A2, b2 = s.get_system()
+            assert np.array_equal(A2, A) and np.array_equal(b2, b)
+
+
+def test_row_dictionary_limits_and_general_rhs(pkg, oracle):
+    """A system whose rows are all different cannot be dictionary-coded and stays on the explicit
+    kernel; one with a right-hand side away from the walls can, with b looked up everywhere."""
+    rng = np.random.default_rng(21)
+    nx, ny = 64, 40
+    D = rng.uniform(0.5, 2.0, size=(ny, nx))            # every cell its own diffusivity
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    x0 = rng.random((ny, nx))
+    want = oracle.sweeps(A, b, x0, 9)
+    with pkg.Solver(nx, ny) as s:
+        s.set_system(A, b, D, 0.0, 1.0)
+        s.set_field(x0)
+        s.sweeps(9)
+        assert s.kernel_in_use() == "explicit"
+        assert_field(s.get_field(), want)
+    pix = rand_mask(rng, nx, ny)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-2)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    b = b.copy()
+    b[::7] += 0.125                                     # sources inside the domain
+    want = oracle.sweeps(A, b, x0, 9)
+    for dict_on in (1, 0):
+        with pkg.Solver(nx, ny) as s:
+            s.set_tuning("dict", dict_on)
+            s.set_system(A, b, D, 0.0, 1.0)
+            s.set_field(x0)
+            s.sweeps(9)
+            assert s.kernel_in_use() == ("matfree_tb" if dict_on else "explicit")
+            assert_field(s.get_field(), want)
 
 
 def test_impermeable_solid_system(pkg, oracle, small_cases):
@@ -475,7 +512,7 @@ def test_impermeable_solid_system(pkg, oracle, small_cases):
     with np.errstate(all="ignore"):
         want = oracle.sweeps(A, b, x0, 50)
     D0 = oracle.fill_D_2phase(pix, Df, 0.0)
-    for kernel in ("explicit", "scalar"):
+    for kernel in ("explicit", "scalar", "auto", "matfree"):
         with pkg.Solver(nx, ny, kernel=kernel) as s:
             s.assemble_from_D(D0, CL, CR, grid=small_cases[name + "_grid"])
             s.set_field(x0)
