@@ -51,11 +51,11 @@ def cpu_baseline(n, seconds_target=12.0):
                       f"host has {os.cpu_count()} logical CPUs"}
 
 
-def bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier):
+def bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier, use_dist):
     """One --size x --size image split into `world` row slabs (RCCL halo exchange per blocked pass)."""
     n, S = args.size, args.sweeps_per_step
     uid = [pkg.rccl_unique_id() if rank == 0 else None]
-    if world > 1:
+    if use_dist:
         dist.broadcast_object_list(uid, src=0)
     s = pkg.SlabRank(n, n, rank, world, uid[0], device=local_rank)
     for kv in args.tune:
@@ -74,7 +74,7 @@ def bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier):
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -89,7 +89,7 @@ def bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier):
                                    f"RCCL send/recv once per temporally blocked pass; step = {S} sweeps",
                        "kernel": "matfree_tb", "sweeps_per_step": S}}), flush=True)
     s.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -127,16 +127,18 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run (any N, also N = 1) use the process group: RCCL over xGMI
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier(device_ids=[local_rank])
 
     n, S = args.size, args.sweeps_per_step
     if args.mode == "slab":
-        return bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier)
+        return bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier, use_dist)
     s = pkg.Solver(n, n, device=local_rank, kernel=args.kernel, nimg=args.batch)
     for kv in args.tune:
         k, v = kv.split("=")
@@ -163,7 +165,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -266,7 +268,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(n)
         print(json.dumps(out), flush=True)
     s.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
