@@ -89,7 +89,10 @@ __device__ __forceinline__ double tb_cell(const double *lut, unsigned off, doubl
 // for a row slab whose array is a window into a taller image; the chunk computes rows
 // [ry0, min(ry0+LY, own_hi)), own_hi being the end of the rows this launch owns (the image in a
 // batch, the slab's own rows -- without its halo -- in a multi-GPU run).
-// (Variants measured and dropped: 4 cells per lane -- 244 VGPRs, 2 waves/SIMD, 20 % slower;
+// (Variants measured and dropped: a 3-row prefetch ring refilled slot by slot instead of the
+// group-of-three double buffer -- fewer VGPRs (94/118 at T=4/6) but 5-8 % slower, the batched
+// loads matter; T = 8 squeezed to 128 VGPRs for 4 waves/SIMD -- spills, 45 % slower;
+// 4 cells per lane -- 244 VGPRs, 2 waves/SIMD, 20 % slower;
 // a skewed pipeline whose T updates per step are independent -- 198 VGPRs, no faster.  The
 // code is deliberately written with double2 values and named slots: an array-of-scalars
 // formulation of the same dataflow made hipcc hoist the lookups to 204 VGPRs.)
