@@ -8,7 +8,10 @@
 // formats keep only 4-7 digits, --json also writes every result at full precision and
 // --field-bin dumps the FP64 concentration field.
 //
-//   deff2d [input.txt] [--device N] [--json results.json] [--field-bin prefix] [--batch-size B]
+//   deff2d [input.txt] [--device N | --devices 0,1,..] [--json results.json] [--field-bin prefix] [--batch-size B]
+//
+// --devices: batch mode over several GPUs from one process -- one host thread and one solver context
+// per listed device, images handed out from a shared counter, no inter-GPU communication.
 //
 // --batch-size B (2-phase batch mode): images of equal size are solved B at a time in one stacked
 // context (deff_create_batch) -- each image still stops by its own convergence rule, the numbers are
@@ -17,11 +20,13 @@
 //
 // This is host-side orchestration only; all arithmetic of the hot path happens behind the C ABI.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/deff_amd.h"
@@ -306,14 +311,21 @@ int main(int argc, char **argv)
 {
     std::string input = "input.txt", json, field_prefix;            // fixed name in the reference, Deff2D.cu:13
     int device = 0, batch_size = 0;
+    std::vector<int> devices;
     for (int a = 1; a < argc; ++a) {
         const std::string s = argv[a];
         if (s == "--device" && a + 1 < argc) device = std::atoi(argv[++a]);
+        else if (s == "--devices" && a + 1 < argc) {                 // e.g. 0,1,2,3,4,5,6,7: one worker per entry
+            for (const char *p = argv[++a]; *p;) {
+                devices.push_back((int)std::strtol(p, const_cast<char **>(&p), 10));
+                if (*p == ',') ++p;
+            }
+        }
         else if (s == "--json" && a + 1 < argc) json = argv[++a];
         else if (s == "--field-bin" && a + 1 < argc) field_prefix = argv[++a];
         else if (s == "--batch-size" && a + 1 < argc) batch_size = std::atoi(argv[++a]);
         else if (s == "-h" || s == "--help") {
-            std::printf("usage: deff2d [input.txt] [--device N] [--json results.json] [--field-bin prefix] [--batch-size B]\n");
+            std::printf("usage: deff2d [input.txt] [--device N] [--json results.json] [--field-bin prefix] [--batch-size B] [--devices 0,1,...]\n");
             return 0;
         } else if (!s.empty() && s[0] != '-') input = s;
         else { std::fprintf(stderr, "deff2d: unknown argument %s\n", s.c_str()); return 2; }
@@ -323,10 +335,8 @@ int main(int argc, char **argv)
     if (!deff::read_input_file(input.c_str(), &o, &err)) { std::fprintf(stderr, "deff2d: %s\n", err.c_str()); return 1; }
     if (o.verbose == 1) deff::print_options(o);
 
-    Session S;
-    S.device = device;
     const int count = o.BatchFlag ? o.NumImg : 1;
-    std::vector<Row> rows;
+    std::vector<Row> rows((size_t)count);
     const bool want_field = o.printCmap == 1 || !field_prefix.empty();
     auto emit_field = [&](int k, const double *x, int nx, int ny) {
         if (o.printCmap == 1) {
@@ -340,55 +350,77 @@ int main(int argc, char **argv)
             if (FILE *f = std::fopen(fn, "wb")) { std::fwrite(x, sizeof(double), (size_t)nx * ny, f); std::fclose(f); }
         }
     };
-    for (int k = 0; k < count;) {
+    auto image_name = [&](int k) {
         char numbered[32];
         std::snprintf(numbered, sizeof numbered, "%05d.jpg", k);     // cuh:1876
-        const std::string name = o.BatchFlag ? std::string(numbered) : o.inputFilename;
-        Image im;
-        if (!load_image(name, &im)) return 1;
-        if (o.verbose == 1) std::printf("Width = %d Height = %d Channel = %d\n", im.W, im.H, im.nChannels);
-        const int nx = im.W * o.MeshIncreaseX, ny = im.H * o.MeshIncreaseY;
-        // 2-phase batch mode: gather following images of the same size into one stacked context
-        int want = 1;
-        if (o.BatchFlag && o.nPhase == 2) {
-            want = batch_size > 0 ? batch_size : (int)std::max<long long>(1, (4ll << 20) / ((long long)nx * ny));
-            if (want > count - k) want = count - k;
+        return o.BatchFlag ? std::string(numbered) : o.inputFilename;
+    };
+
+    // Work items = runs of `group` consecutive images (2-phase batch mode: solved together in one
+    // stacked context when they have the same size).  One host thread per device takes items from
+    // a shared counter -- whole images per GPU, no communication -- and JPEG
+    // decoding, flood fill and uploads of one item overlap the other devices' solves.  Rows land in
+    // the table by image index, so the output does not depend on the number of devices.
+    int group = 1;
+    if (o.BatchFlag && o.nPhase == 2) {
+        group = batch_size;
+        if (group <= 0) {
+            Image first;
+            if (!load_image(image_name(0), &first)) return 1;
+            const long long cells = (long long)first.W * o.MeshIncreaseX * first.H * o.MeshIncreaseY;
+            group = (int)std::max<long long>(1, (4ll << 20) / std::max<long long>(1, cells));
         }
-        if (want > 1) {
-            std::vector<Image> group;
-            group.push_back(std::move(im));
-            while ((int)group.size() < want) {
-                std::snprintf(numbered, sizeof numbered, "%05d.jpg", k + (int)group.size());
-                Image nxt;
-                if (!load_image(numbered, &nxt)) return 1;
-                if (nxt.W != group[0].W || nxt.H != group[0].H) break;       // different size: starts the next group
-                group.push_back(std::move(nxt));
-            }
-            std::vector<Row> grows(group.size());
-            for (size_t q = 0; q < group.size(); ++q) {
-                std::snprintf(numbered, sizeof numbered, "%05d.jpg", k + (int)q);
-                grows[q].name = numbered;
-            }
-            std::vector<double> fields;
-            if (!solve_2phase_group(S, group, o, grows.data(), want_field ? &fields : nullptr)) return 1;
-            for (size_t q = 0; q < group.size(); ++q) {
-                if (want_field) emit_field(k + (int)q, fields.data() + q * (size_t)nx * ny, nx, ny);
-                rows.push_back(grows[q]);
-            }
-            k += (int)group.size();
-            continue;
-        }
-        Row row;
-        row.name = name;
-        std::vector<double> field;
-        const bool ok = (o.nPhase == 2) ? solve_2phase(S, im, o, !o.BatchFlag, &row, want_field ? &field : nullptr)
-                                        : solve_3phase(S, im, o, &row, want_field ? &field : nullptr);
-        if (!ok) return 1;
-        if (o.verbose == 1 && o.nPhase == 2) std::printf("Porosity = %g\n", row.porosity);
-        if (want_field) emit_field(k, field.data(), nx, ny);
-        rows.push_back(row);
-        ++k;
     }
+    const int items = (count + group - 1) / group;
+    std::atomic<int> next_item{0};
+    std::atomic<bool> failed{false};
+    auto worker = [&](int dev) {
+        Session S;
+        S.device = dev;
+        for (;;) {
+            const int w = next_item.fetch_add(1);
+            if (w >= items || failed.load()) break;
+            const int k0 = w * group, k1 = std::min(count, k0 + group);
+            std::vector<Image> ims((size_t)(k1 - k0));
+            for (int k = k0; k < k1; ++k) {
+                if (!load_image(image_name(k), &ims[(size_t)(k - k0)])) { failed = true; return; }
+                if (o.verbose == 1)
+                    std::printf("Width = %d Height = %d Channel = %d\n", ims[(size_t)(k - k0)].W, ims[(size_t)(k - k0)].H,
+                                ims[(size_t)(k - k0)].nChannels);
+            }
+            for (int k = k0; k < k1;) {
+                // maximal run of equally sized images starting at k
+                int e = k + 1;
+                while (e < k1 && ims[(size_t)(e - k0)].W == ims[(size_t)(k - k0)].W && ims[(size_t)(e - k0)].H == ims[(size_t)(k - k0)].H) ++e;
+                const Image &im0 = ims[(size_t)(k - k0)];
+                const int nx = im0.W * o.MeshIncreaseX, ny = im0.H * o.MeshIncreaseY;
+                for (int q = k; q < e; ++q) rows[(size_t)q].name = image_name(q);
+                std::vector<double> fields;
+                bool ok;
+                if (e - k > 1) {
+                    std::vector<Image> run(ims.begin() + (k - k0), ims.begin() + (e - k0));
+                    ok = solve_2phase_group(S, run, o, &rows[(size_t)k], want_field ? &fields : nullptr);
+                } else if (o.nPhase == 2) {
+                    ok = solve_2phase(S, im0, o, !o.BatchFlag, &rows[(size_t)k], want_field ? &fields : nullptr);
+                    if (ok && o.verbose == 1) std::printf("Porosity = %g\n", rows[(size_t)k].porosity);
+                } else {
+                    ok = solve_3phase(S, im0, o, &rows[(size_t)k], want_field ? &fields : nullptr);
+                }
+                if (!ok) { failed = true; return; }
+                if (want_field)
+                    for (int q = k; q < e; ++q) emit_field(q, fields.data() + (size_t)(q - k) * nx * ny, nx, ny);
+                k = e;
+            }
+        }
+    };
+    if (devices.size() <= 1 || items <= 1) {
+        worker(devices.empty() ? device : devices[0]);
+    } else {
+        std::vector<std::thread> pool;
+        for (int dev : devices) pool.emplace_back(worker, dev);
+        for (std::thread &t : pool) t.join();
+    }
+    if (failed.load()) return 1;
     write_csv(o, rows);                                              // after ALL images, like the reference (cuh:2051)
     if (!json.empty()) write_json(json, o, rows);
     return 0;

@@ -153,16 +153,16 @@ def test_driver_batch_groups_images(built, tmp_path, oracle):
                  OutputName="out.csv", printCMap=0, Convergence="1e-4", MaxIter="2e5", Verbose=0, RunBatch=1,
                  NumImages=7)
     results = {}
-    for bs in (3, 1):
-        r = subprocess.run([EXE, "input.txt", "--json", f"res{bs}.json", "--batch-size", str(bs)], cwd=tmp_path,
-                           capture_output=True, text=True, timeout=600)
+    for bs, extra in ((3, []), (1, []), (2, ["--devices", "0,0,0"])):     # 2: three worker threads on one GPU
+        r = subprocess.run([EXE, "input.txt", "--json", f"res{bs}.json", "--batch-size", str(bs)] + extra,
+                           cwd=tmp_path, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr + r.stdout
         results[bs] = json.load(open(tmp_path / f"res{bs}.json"))["results"]
     for k in range(7):
         D = oracle.fill_D_2phase(pixs[k], 1.0, 1e-2)
         A, b = oracle.discretize(D, 0.0, 1.0)
         it, deff, conv, _, _, _ = oracle.jacobi(A, b, oracle.linear_guess(96, 64, 0.0, 1.0), D, 0.0, 1.0, 1e-4, 200000)
-        for bs in (3, 1):
+        for bs in (3, 1, 2):
             res = results[bs][k]
             assert res["image"] == f"{k:05d}.jpg"
             assert (res["iterations"], res["Deff"], res["converge"]) == (it, deff, conv), (bs, k)
