@@ -133,6 +133,7 @@ struct deff_ctx {
     int nt_explicit = 1;                         // non-temporal coefficient loads in the explicit kernels
     int serpentine = 1;                          // alternate the tile walk direction from sweep to sweep
     int tb_T = 0, tb_LY = 0, tb_wg = 0;          // temporal blocking: sweeps per pass, rows per chunk, workgroups
+    unsigned long long *tb_stamps = nullptr;     // diagnostics: per wave-tile start/end clocks (deff_debug_tb_stamps)
     int tb_xmajor = 1;                           // wave-tile numbering of the temporally blocked kernel
     int64_t last_launches = 0;                   // sweep-kernel launches of the last deff_sweeps()/deff_solve()
 };
@@ -1021,7 +1022,7 @@ static inline void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl)
     hipLaunchKernelGGL((k_sweep_matfree_tb<T_, C_, G_>), dim3(pl.tblocks), dim3(256), 0, c->stream, c->lut,    \
                        c->code, xin, xout, c->nx, c->mesh_ny, c->ny, c->dom_lo, c->own_lo, c->own_h, pl.tcpi, \
                        mask, pl.LY, pl.ntx, pl.tgx, pl.tgy, flip, c->tb_xmajor, c->lut_allb ? 1 : 0,         \
-                       c->lut_nrows, pl.omw)
+                       c->lut_nrows, pl.omw, c->tb_stamps)
     TB_DISPATCH(pl.T, pl.CPL, pl.guard, LAUNCH_TB);
 #undef LAUNCH_TB
     c->cur ^= 1;
@@ -1185,6 +1186,30 @@ extern "C" int deff_solve(deff_ctx *c, double omega, double tol, int64_t max_ite
 {
     if (c && c->nimg != 1) return fail(DEFF_EINVAL, "context holds %d images: use deff_solve_batch()", c->nimg);
     return deff_solve_batch(c, omega, tol, max_iter, check_every, out, MFL, MFR);
+}
+
+// Diagnostics: time-stamp every wave tile of ONE temporally blocked pass (100 MHz wall clock ticks).
+// out[2*k], out[2*k+1] = start, end of wave tile k; *ntiles = number of tiles (call with out = NULL
+// to size the buffer).  Advances the field by one pass.
+extern "C" int deff_debug_tb_stamps(deff_ctx *c, double omega, unsigned long long *out, int *ntiles)
+{
+    if (!c || !ntiles) return fail(DEFF_EINVAL, "NULL argument");
+    TRY(use_device(c));
+    SweepPlan pl;
+    TRY(plan_sweeps(c, omega, &pl));
+    if (pl.kernel != DEFF_KERNEL_MATFREE_TB) return fail(DEFF_ESTATE, "not on the temporally blocked kernel");
+    const int n = pl.ntx * pl.tgy;
+    *ntiles = n;
+    if (!out) return DEFF_OK;
+    HIP_TRY(hipMalloc((void **)&c->tb_stamps, sizeof(unsigned long long) * 2 * n));
+    HIP_TRY(hipMemsetAsync(c->tb_stamps, 0, sizeof(unsigned long long) * 2 * n, c->stream));
+    enqueue_tb_pass(c, pl);
+    hipError_t e = hipMemcpyAsync(out, c->tb_stamps, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(c->tb_stamps);
+    c->tb_stamps = nullptr;
+    if (e != hipSuccess) return fail(DEFF_EHIP, "stamp readback failed: %s", hipGetErrorString(e));
+    return DEFF_OK;
 }
 
 extern "C" int deff_set_progress(deff_ctx *c, deff_progress_fn fn, void *user)

@@ -133,6 +133,11 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
         nx_c[k] = ok ? *reinterpret_cast<const uint32_t *>(code + p) : 0u;   // rows / lanes outside the mesh: zero row
     }
 
+    // (Measured with the tile time stamps, tools/tb_stamps.py: waves sharing a SIMD are served
+    // oldest-first, so identical tiles finish between 82 and 128 us inside one T = 8 launch.  A
+    // self-balancing s_setprio -- each wave lowering its priority as it advances -- narrowed that to
+    // 88..119 us but left the back-to-back launch rate unchanged (the SIMDs are throughput-bound;
+    // the early finishers' share goes to the rest), so it is not kept.)
     for (int r = r_begin; r < r_end; r += 3) {
         double2 cur_x[3];
         unsigned cur_c[3];
@@ -198,7 +203,8 @@ __global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restri
                                                           int own_h, int cpi,
                                                           const uint8_t *__restrict__ active,
                                                           int LY, int ntx, int nbt, int gy, int flip,
-                                                          int xmajor, int allb, int nrows, double omw)
+                                                          int xmajor, int allb, int nrows, double omw,
+                                                          unsigned long long *__restrict__ stamps)
 {
     static_assert(T >= 1 && T <= 8 && CPL == 2, "unsupported T / cells per lane");
     __shared__ double lut[LUT_DOUBLES];
@@ -215,6 +221,9 @@ __global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restri
     const unsigned xcd = blockIdx.x & 7u;
     const unsigned nper = gridDim.x >> 3;
 
+    // diagnostics only (tools/tb_stamps.py): wall-clock start / end of every wave tile; the buffer is
+    // written by lane 0 after the tile and read by nobody on the device
+    const unsigned long long t_begin = stamps ? wall_clock64() : 0ull;
     for (unsigned kk = blockIdx.x >> 3; kk < per; kk += nper) {
         const unsigned bt = xcd * per + (flip ? per - 1u - kk : kk);
         if (bt >= total) continue;
@@ -235,6 +244,10 @@ __global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restri
             tb_strip<T, GUARD, true>(lut, code, x, xnew, nx, ny, row_lo, own0 + own_h, tx, ry0, LY, lane, omw);
         else
             tb_strip<T, GUARD, false>(lut, code, x, xnew, nx, ny, row_lo, own0 + own_h, tx, ry0, LY, lane, omw);
+        if (stamps && lane == 0) {
+            stamps[2 * (size_t)wt] = t_begin;
+            stamps[2 * (size_t)wt + 1] = wall_clock64();
+        }
     }
 }
 

@@ -181,6 +181,9 @@ int deff_slab_rank_sweeps(deff_slab_rank *s, int64_t n, double omega, float *ms)
 int deff_slab_rank_solve(deff_slab_rank *s, double omega, double tol, int64_t max_iter,
                          int64_t check_every, deff_result *out, double *MFL, double *MFR);
 
+/* diagnostics: wall-clock (100 MHz) start/end of every wave tile of one temporally blocked pass */
+int deff_debug_tb_stamps(deff_ctx *ctx, double omega, unsigned long long *out, int *ntiles);
+
 /* raw device pointers for zero-copy interop (torch tensors, RCCL): current field,
  * and the byte pitch between rows (nx*8: rows are dense) */
 int deff_device_field(deff_ctx *ctx, void **d_x, size_t *row_pitch_bytes);
