@@ -234,14 +234,14 @@ def main():
             },
         }
         if kernel_used in ("matfree", "matfree_tb"):
-            # this kernel never materialises A: its own compulsory traffic is x 8 + code 1 read, xNew 8
+            # this kernel never materialises A: its own compulsory traffic is x 8 + code 2 read, xNew 8
             # written per cell per LAUNCH (a temporally blocked launch does sweeps_per_launch sweeps on it)
-            own = 17.0 * cells
+            own = 18.0 * cells
             out["roofline"]["own_model"] = {
                 "bytes_per_launch": own,
                 "achieved": own / launch_s / 1e9,
                 "frac": own / launch_s / 1e9 / HBM_PEAK_GBS,
-                "note": "matrix-free: coefficients come from a 1-byte phase code through LDS tables; frac of the "
+                "note": "matrix-free: coefficients come from a 16-bit row code through an LDS row dictionary; frac of the "
                         "64-B model above can exceed 1 because those bytes are never moved",
             }
         tr = traffic_of(kernel_used)

@@ -17,8 +17,8 @@
 //   k_sweep_explicit  2 x R cells / thread (16-B accesses), SoA coefficient
 //                     streams, all loads of a register tile issued up front:
 //                     64 B/cell/sweep of HBM
-//   k_sweep_matfree   coefficients looked up in an LDS table from a 1-byte
-//                     phase code, persistent workgroups: 17 B/cell/sweep of HBM
+//   k_sweep_matfree   coefficients looked up in the row dictionary (LDS) by a 16-bit
+//                     code per cell, persistent workgroups: 18 B/cell/sweep of HBM
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -9,20 +9,21 @@
 //
 // Structure: every WAVE is independent.  A wave owns a strip of 128 columns
 // (2 per lane) and streams down the rows of its chunk.  Per input row it
-//   level 0   loads the row of x (16 B per lane, coalesced) and its phase codes,
+//   level 0   loads the row of x (16 B per lane, coalesced) and its row codes (4 B per lane),
 //   level t   (t = 1..T) computes row r-t of sweep t from the three newest rows
 //             of sweep t-1, all held in registers (a 3-row window per level);
 //             W/E neighbours come from the adjacent lanes by DPP wave shifts,
-//             N/S from the window; coefficients from the LDS lookup tables,
+//             N/S from the window; coefficients from the row dictionary in LDS,
 //   level T   is stored (16 B per lane).
 // After t sweeps the outermost t columns/rows of a strip are stale, so a strip
 // produces 128 - 2T valid columns and needs T extra rows above and below its
 // chunk: neighbouring strips overlap by 2T and recompute the overlap instead of
 // synchronising.  No barrier, no inter-wave traffic inside the row loop.
 //
-// HBM traffic per cell per sweep: (8 + 1) / T / efficiency read + 8 / T
-// written -- ~5 B at T = 4 against 17 B for the single-sweep matrix-free
-// kernel and 64 B for explicit coefficients; the kernel is VALU/LDS-bound.
+// HBM traffic per cell per sweep: (8 + 2) / T / efficiency read + 8 / T
+// written -- 2.7 B measured at T = 8 against 18 B for the single-sweep
+// matrix-free kernel and 64 B for explicit coefficients; the kernel is bound by
+// FP64 VALU issue and LDS lookups (SQ counters: VALU ~55-60 % busy, LDS ~40 %).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -43,7 +43,7 @@ extern "C" {
 #define DEFF_KERNEL_AUTO       0
 #define DEFF_KERNEL_EXPLICIT   1   /* SoA coefficient streams, 64 B/cell/sweep */
 #define DEFF_KERNEL_SCALAR     2   /* 1 cell/thread, any nx; correctness fallback */
-#define DEFF_KERNEL_MATFREE    3   /* coefficients from the phase code, 17 B/cell/sweep */
+#define DEFF_KERNEL_MATFREE    3   /* rows from the dictionary by a 16-bit code, 18 B/cell/sweep */
 #define DEFF_KERNEL_MATFREE_TB 4   /* matrix-free, several sweeps per HBM pass */
 
 typedef struct deff_ctx deff_ctx;
