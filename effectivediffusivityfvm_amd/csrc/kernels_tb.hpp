@@ -90,7 +90,9 @@ __device__ __forceinline__ double tb_cell(const double *lut, unsigned off, doubl
 // for a row slab whose array is a window into a taller image; the chunk computes rows
 // [ry0, min(ry0+LY, own_hi)), own_hi being the end of the rows this launch owns (the image in a
 // batch, the slab's own rows -- without its halo -- in a multi-GPU run).
-// (Variants measured and dropped: a 3-row prefetch ring refilled slot by slot instead of the
+// (Variants measured and dropped: software-pipelining the table lookups one sweep level ahead of
+// the arithmetic -- 152/172/190 VGPRs at T=4/6/8, +4 % at T=4, -8 % / -4 % at T=6 / T=8: once more
+// instruction-level parallelism bought with occupancy is a wash; a 3-row prefetch ring refilled slot by slot instead of the
 // group-of-three double buffer -- fewer VGPRs (94/118 at T=4/6) but 5-8 % slower, the batched
 // loads matter; T = 8 squeezed to 128 VGPRs for 4 waves/SIMD -- spills, 45 % slower;
 // 4 cells per lane -- 244 VGPRs, 2 waves/SIMD, 20 % slower;
