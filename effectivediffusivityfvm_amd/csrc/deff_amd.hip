@@ -1301,6 +1301,17 @@ extern "C" int deff_slab_group_create(int nslabs, const int *devices, int nx, in
         g->done.push_back(ev);
     }
     if (rc != DEFF_OK) { deff_slab_group_destroy(g); return rc; }
+    // direct xGMI copies between neighbouring slabs' devices (staged through the host otherwise)
+    for (int r = 0; r + 1 < nslabs; ++r) {
+        const int a = g->ctx[r]->device, b = g->ctx[r + 1]->device;
+        if (a == b) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) {
+            (void)hipSetDevice(a); (void)hipDeviceEnablePeerAccess(b, 0);
+            (void)hipSetDevice(b); (void)hipDeviceEnablePeerAccess(a, 0);
+            (void)hipGetLastError();                 // "already enabled" is fine
+        }
+    }
     *out = g;
     return DEFF_OK;
 }
