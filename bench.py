@@ -183,6 +183,12 @@ def main():
         explicit = (ems * 1e-3 / args.explicit_sweeps, s.kernel_in_use())
         s.set_kernel(args.kernel)
 
+    # second reported row: plain Jacobi, omega = 1 (updateX_V1's arithmetic), same kernel
+    omega1_ms = None
+    if abs(args.omega - 1.0) > 1e-12:
+        s.sweeps(sweeps_per_launch * 4, 1.0)
+        omega1_ms = s.sweeps(S, 1.0)
+
     if rank == 0:
         cells = float(n) * n * args.batch
         total_launches = args.steps * launches
@@ -244,6 +250,9 @@ def main():
                 "note": "matrix-free: coefficients come from a 16-bit row code through an LDS row dictionary; frac of the "
                         "64-B model above can exceed 1 because those bytes are never moved",
             }
+        if omega1_ms:
+            out["jacobi_omega_1"] = {"value": cells * S / (omega1_ms * 1e-3) / 1e6, "unit": "Mcells*iter/s",
+                                     "sample": f"{S} sweeps with omega = 1 (plain Jacobi, updateX_V1), same image, one GPU"}
         tr = traffic_of(kernel_used)
         if tr:
             out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]

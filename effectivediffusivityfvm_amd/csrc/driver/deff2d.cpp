@@ -18,6 +18,10 @@
 // those of the one-at-a-time run, but small images fill the GPU.  Default: as many images as bring
 // the stack to ~4 Mi cells (1 for images that large).
 //
+// --progress file: checkpoint/resume for long batches (the reference keeps all results in memory
+// and loses them if interrupted, doc section 3.6): every finished image appends one line to `file`;
+// on start, images already listed there are not solved again, their rows are taken from the file.
+//
 // This is host-side orchestration only; all arithmetic of the hot path happens behind the C ABI.
 #include <algorithm>
 #include <atomic>
@@ -25,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -307,11 +312,57 @@ static void write_json(const std::string &path, const Options &o, const std::vec
     std::fclose(f);
 }
 
+// One line per finished image: index and every field of its row, doubles as hex floats (exact).
+static void progress_append(const std::string &path, int k, const Row &r)
+{
+    if (path.empty()) return;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    FILE *f = std::fopen(path.c_str(), "a");
+    if (!f) return;
+    std::fprintf(f, "%d %a %a %a %a %a %a %d %d %ld %zu", k, r.porosity, r.SVF, r.LVF, r.deff, r.seconds, r.conv, r.path,
+                 r.nElements, r.iters, r.stages.size());
+    for (long st : r.stages) std::fprintf(f, " %ld", st);
+    std::fprintf(f, "\n");
+    std::fclose(f);
+}
+
+static void progress_load(const std::string &path, std::vector<Row> &rows, std::vector<char> &done)
+{
+    if (path.empty()) return;
+    FILE *f = std::fopen(path.c_str(), "r");
+    if (!f) return;
+    char line[4096];
+    while (std::fgets(line, sizeof line, f)) {
+        int k = -1, consumed = 0;
+        Row r;
+        size_t ns = 0;
+        if (std::sscanf(line, "%d %la %la %la %la %la %la %d %d %ld %zu%n", &k, &r.porosity, &r.SVF, &r.LVF, &r.deff, &r.seconds,
+                        &r.conv, &r.path, &r.nElements, &r.iters, &ns, &consumed) != 11)
+            continue;                                            // torn last line of an interrupted run
+        if (k < 0 || k >= (int)rows.size()) continue;
+        const char *p = line + consumed;
+        bool ok = true;
+        for (size_t q = 0; q < ns; ++q) {
+            char *e = nullptr;
+            const long v = std::strtol(p, &e, 10);
+            if (e == p) { ok = false; break; }
+            r.stages.push_back(v);
+            p = e;
+        }
+        if (!ok) continue;
+        rows[(size_t)k] = r;
+        done[(size_t)k] = 1;
+    }
+    std::fclose(f);
+}
+
 int main(int argc, char **argv)
 {
     std::string input = "input.txt", json, field_prefix;            // fixed name in the reference, Deff2D.cu:13
     int device = 0, batch_size = 0;
     std::vector<int> devices;
+    std::string progress_path;
     for (int a = 1; a < argc; ++a) {
         const std::string s = argv[a];
         if (s == "--device" && a + 1 < argc) device = std::atoi(argv[++a]);
@@ -324,8 +375,9 @@ int main(int argc, char **argv)
         else if (s == "--json" && a + 1 < argc) json = argv[++a];
         else if (s == "--field-bin" && a + 1 < argc) field_prefix = argv[++a];
         else if (s == "--batch-size" && a + 1 < argc) batch_size = std::atoi(argv[++a]);
+        else if (s == "--progress" && a + 1 < argc) progress_path = argv[++a];
         else if (s == "-h" || s == "--help") {
-            std::printf("usage: deff2d [input.txt] [--device N] [--json results.json] [--field-bin prefix] [--batch-size B] [--devices 0,1,...]\n");
+            std::printf("usage: deff2d [input.txt] [--device N] [--json results.json] [--field-bin prefix] [--batch-size B] [--devices 0,1,...] [--progress file]\n");
             return 0;
         } else if (!s.empty() && s[0] != '-') input = s;
         else { std::fprintf(stderr, "deff2d: unknown argument %s\n", s.c_str()); return 2; }
@@ -371,6 +423,10 @@ int main(int argc, char **argv)
             group = (int)std::max<long long>(1, (4ll << 20) / std::max<long long>(1, cells));
         }
     }
+    std::vector<char> done((size_t)count, 0);
+    progress_load(progress_path, rows, done);
+    for (int k = 0; k < count; ++k)
+        if (done[(size_t)k]) rows[(size_t)k].name = image_name(k);
     const int items = (count + group - 1) / group;
     std::atomic<int> next_item{0};
     std::atomic<bool> failed{false};
@@ -381,6 +437,9 @@ int main(int argc, char **argv)
             const int w = next_item.fetch_add(1);
             if (w >= items || failed.load()) break;
             const int k0 = w * group, k1 = std::min(count, k0 + group);
+            bool all_done = true;
+            for (int k = k0; k < k1; ++k) all_done = all_done && done[(size_t)k];
+            if (all_done) continue;                              // resumed run: this item is already in the progress file
             std::vector<Image> ims((size_t)(k1 - k0));
             for (int k = k0; k < k1; ++k) {
                 if (!load_image(image_name(k), &ims[(size_t)(k - k0)])) { failed = true; return; }
@@ -394,7 +453,7 @@ int main(int argc, char **argv)
                 while (e < k1 && ims[(size_t)(e - k0)].W == ims[(size_t)(k - k0)].W && ims[(size_t)(e - k0)].H == ims[(size_t)(k - k0)].H) ++e;
                 const Image &im0 = ims[(size_t)(k - k0)];
                 const int nx = im0.W * o.MeshIncreaseX, ny = im0.H * o.MeshIncreaseY;
-                for (int q = k; q < e; ++q) rows[(size_t)q].name = image_name(q);
+                for (int q = k; q < e; ++q) { rows[(size_t)q] = Row(); rows[(size_t)q].name = image_name(q); }   // also drops resumed leftovers
                 std::vector<double> fields;
                 bool ok;
                 if (e - k > 1) {
@@ -407,6 +466,7 @@ int main(int argc, char **argv)
                     ok = solve_3phase(S, im0, o, &rows[(size_t)k], want_field ? &fields : nullptr);
                 }
                 if (!ok) { failed = true; return; }
+                for (int q = k; q < e; ++q) progress_append(progress_path, q, rows[(size_t)q]);
                 if (want_field)
                     for (int q = k; q < e; ++q) emit_field(q, fields.data() + (size_t)(q - k) * nx * ny, nx, ny);
                 k = e;

@@ -74,6 +74,20 @@ def test_jpeg_decoder_rejects_what_the_reference_rejects(built, tmp_path):
     assert mine.shape == (37, 53) and np.abs(mine.astype(int) - ref.astype(int)).max() <= 1
 
 
+def test_input_file_parsing_matches_reference_conventions(built, tmp_path):
+    """Keys with their colon, any order, numeric values through double (MaxIter: 5e5), unknown
+    lines ignored (the decorative 'Input File:' header), file names as second token; defaults for
+    what is missing.  Checked through the driver's Verbose echo (it fails later for lack of an image)."""
+    open(tmp_path / "in.txt", "w").write(
+        "Input File:\nVerbose: 1\nMaxIter: 5e5\nsomething else entirely\nDf: 2.5\nPhases: 3\nDg: 1237500\n"
+        "InputName: nothere.jpg  trailing words\nConvergence: 1e-5\nMeshAmpX: 2\n")
+    r = subprocess.run([EXE, str(tmp_path / "in.txt")], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 1 and "cannot open nothere.jpg" in r.stderr
+    out = r.stdout
+    assert "Phases = 3" in out and "Df = 2.5, Dg = 1.2375e+06" in out and "MaxIter = 500000" in out
+    assert "Mesh amplification = 2 x 1" in out and "Convergence = 1e-05" in out and "Input = nothere.jpg" in out
+
+
 def _write_input(path, **kv):
     lines = ["Input File:"] + [f"{k}: {v}" for k, v in kv.items()]
     open(path, "w").write("\n".join(lines) + "\n")
@@ -153,11 +167,24 @@ def test_driver_batch_groups_images(built, tmp_path, oracle):
                  OutputName="out.csv", printCMap=0, Convergence="1e-4", MaxIter="2e5", Verbose=0, RunBatch=1,
                  NumImages=7)
     results = {}
-    for bs, extra in ((3, []), (1, []), (2, ["--devices", "0,0,0"])):     # 2: three worker threads on one GPU
+    # 2: three worker threads on one GPU, writing a progress file
+    for bs, extra in ((3, []), (1, []), (2, ["--devices", "0,0,0", "--progress", "prog.txt"])):
         r = subprocess.run([EXE, "input.txt", "--json", f"res{bs}.json", "--batch-size", str(bs)] + extra,
                            cwd=tmp_path, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr + r.stdout
         results[bs] = json.load(open(tmp_path / f"res{bs}.json"))["results"]
+    # resume: drop the last two lines of the progress file (an "interrupted" run) plus a torn line;
+    # only those images are solved again and the result is the same table
+    lines = open(tmp_path / "prog.txt").read().splitlines()
+    assert len(lines) == 7
+    open(tmp_path / "prog.txt", "w").write("\n".join(lines[:5]) + "\n3 0x1.8p+0 torn")
+    r = subprocess.run([EXE, "input.txt", "--json", "res_resume.json", "--batch-size", "2", "--progress", "prog.txt"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    resumed = json.load(open(tmp_path / "res_resume.json"))["results"]
+    strip = lambda rows: [{k: v for k, v in row.items() if k != "Time"} for row in rows]
+    assert strip(resumed) == strip(results[2])
+    assert len(open(tmp_path / "prog.txt").read().splitlines()) >= 7
     for k in range(7):
         D = oracle.fill_D_2phase(pixs[k], 1.0, 1e-2)
         A, b = oracle.discretize(D, 0.0, 1.0)
