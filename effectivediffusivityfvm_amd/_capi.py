@@ -28,7 +28,7 @@ SYMBOLS = [
     "deff_rccl_unique_id", "deff_slab_rank_create", "deff_slab_rank_destroy", "deff_slab_rank_layout",
     "deff_slab_rank_window", "deff_slab_rank_context", "deff_slab_rank_set_image_window",
     "deff_slab_rank_synth_image", "deff_slab_rank_get_field", "deff_slab_rank_sweeps", "deff_slab_rank_solve",
-    "deff_debug_tb_stamps", "deff_flux", "deff_set_progress", "deff_last_launches", "deff_device_field", "deff_synchronize",
+    "deff_solve_stream", "deff_get_slot_field", "deff_debug_tb_stamps", "deff_flux", "deff_set_progress", "deff_last_launches", "deff_device_field", "deff_synchronize",
 ]
 
 
@@ -44,6 +44,8 @@ class Result(C.Structure):
 
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int64, C.c_double, C.c_double, C.c_void_p)
+NEXT_IMAGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int64))
+IMAGE_DONE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int, C.POINTER(Result))
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 _lib = None
@@ -127,6 +129,10 @@ def load():
     L.deff_slab_rank_sweeps.argtypes = [ctx, C.c_int64, C.c_double, C.POINTER(C.c_float)]
     L.deff_slab_rank_solve.argtypes = [ctx, C.c_double, C.c_double, C.c_int64, C.c_int64, C.POINTER(Result),
                                        C.c_void_p, C.c_void_p]
+    L.deff_solve_stream.argtypes = [ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                    C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int64, NEXT_IMAGE_FN,
+                                    IMAGE_DONE_FN, C.c_void_p]
+    L.deff_get_slot_field.argtypes = [ctx, C.c_int, _dp]
     L.deff_debug_tb_stamps.argtypes = [ctx, C.c_double, C.c_void_p, C.POINTER(C.c_int)]
     L.deff_device_field.argtypes = [ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.deff_synchronize.argtypes = [ctx]

@@ -119,6 +119,7 @@ struct deff_ctx {
     uint8_t *active = nullptr;
     std::vector<uint8_t> active_h, buf_of;
     bool masked = false;
+    bool in_stream = false;         // inside deff_solve_stream: buf_of[] is current for every slot
 
     // scratch for chunked uploads (AoS import, D upload)
     void *scratch = nullptr;
@@ -134,6 +135,7 @@ struct deff_ctx {
     int serpentine = 1;                          // alternate the tile walk direction from sweep to sweep
     int tb_T = 0, tb_LY = 0, tb_wg = 0;          // temporal blocking: sweeps per pass, rows per chunk, workgroups
     unsigned long long *tb_stamps = nullptr;     // diagnostics: per wave-tile start/end clocks (deff_debug_tb_stamps)
+    int tb_wall_halo = 2;                        // strip placement: 1 = halo also outside the walls, 0 = not, 2 = whichever needs fewer strips
     int tb_xmajor = 1;                           // wave-tile numbering of the temporally blocked kernel
     int64_t last_launches = 0;                   // sweep-kernel launches of the last deff_sweeps()/deff_solve()
 };
@@ -360,6 +362,7 @@ extern "C" int deff_set_tuning(deff_ctx *c, const char *key, int value)
     else if (!strcmp(key, "tb_LY")) c->tb_LY = value;
     else if (!strcmp(key, "dict")) c->dict_enabled = value ? 1 : 0;
     else if (!strcmp(key, "tb_xmajor")) c->tb_xmajor = value ? 1 : 0;
+    else if (!strcmp(key, "tb_wall_halo")) c->tb_wall_halo = value > 2 ? 2 : value;
     else if (!strcmp(key, "tb_wg")) c->tb_wg = (value + 7) / 8 * 8;
     else return fail(DEFF_EINVAL, "unknown tuning key '%s'", key);
     return DEFF_OK;
@@ -749,6 +752,7 @@ struct SweepPlan {
     int rows = 0, cpi = 0, gx = 0, gy = 0, blocks = 0;   // single-sweep kernels (cpi: row tiles per image)
     // temporally blocked kernel
     int T = 0, CPL = 2, LY = 0, tcpi = 0, ntx = 0, tgx = 0, tgy = 0, tblocks = 0;
+    int shift = 0;                                        // column shift of the strips (0: no halo outside the walls)
     int T_override = 0;                                   // slab mode plans a T = 1 pass for remainders
     bool guard = false;
 };
@@ -897,8 +901,17 @@ static int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             T = T >= 8 ? 8 : T >= 6 ? 6 : T >= 4 ? 4 : T >= 2 ? 2 : 1;
             pl->T = T;
             pl->CPL = 2;
-            const int wout = 64 * pl->CPL - 2 * ((T + 1) & ~1);
-            pl->ntx = (c->nx + wout - 1) / wout;
+            // strips of 128 columns overlapping by 2*HW; a mesh wall needs no halo (kernels_tb.hpp)
+            const int hw = (T + 1) & ~1, wout = 64 * pl->CPL - 2 * hw;
+            // placement A: every strip carries its halo, also outside the first column; placement B:
+            // no halo outside a wall (kernels_tb.hpp).  B needs fewer strips for narrow images
+            // (a 128-column image is ONE strip: 2x on dataset batches); where the counts tie, A measured
+            // equal or up to 5 % faster in one process (T = 8 at 4096^2), so B is used only when it wins.
+            const int ntx_a = (c->nx + wout - 1) / wout;
+            const int ntx_b = c->nx <= 64 * pl->CPL ? 1 : (c->nx - 64 * pl->CPL + wout - 1) / wout + 1;
+            const bool use_b = c->tb_wall_halo == 0 ? true : (c->tb_wall_halo == 1 ? false : ntx_b < ntx_a);
+            pl->shift = use_b ? 0 : hw;
+            pl->ntx = use_b ? ntx_b : ntx_a;
             // Rows per chunk.  Workgroups are persistent and tiles cost the same, so the
             // pass takes rounds x (LY + 2T) row steps, where one round is as many block
             // tiles as are resident at once.  Pick the (rounds, LY) pair minimising that.
@@ -1022,7 +1035,7 @@ static inline void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl)
     hipLaunchKernelGGL((k_sweep_matfree_tb<T_, C_, G_>), dim3(pl.tblocks), dim3(256), 0, c->stream, c->lut,    \
                        c->code, xin, xout, c->nx, c->mesh_ny, c->ny, c->dom_lo, c->own_lo, c->own_h, pl.tcpi, \
                        mask, pl.LY, pl.ntx, pl.tgx, pl.tgy, flip, c->tb_xmajor, c->lut_allb ? 1 : 0,         \
-                       c->lut_nrows, pl.omw, c->tb_stamps)
+                       c->lut_nrows, pl.shift, pl.omw, c->tb_stamps)
     TB_DISPATCH(pl.T, pl.CPL, pl.guard, LAUNCH_TB);
 #undef LAUNCH_TB
     c->cur ^= 1;
@@ -1178,6 +1191,184 @@ extern "C" int deff_solve_batch(deff_ctx *c, double omega, double tol, int64_t m
         out[k].conv = conv[k];
         out[k].loop_ms = ms;                                         // the batch shares one loop
     }
+    return DEFF_OK;
+}
+
+// ---- streaming batch ---------------------------------------------------------------------
+//
+// Dataset generation with images that converge after very different numbers of sweeps: a plain
+// batch drains (its slots empty one by one, measured 376 of ~1000 G cells*iter/s end to end on 512
+// images of 128^2).  Here a slot whose image has finished is REFILLED with the next image.  To keep
+// every image on the reference's schedule -- checks after its own sweeps 1, C+1, 2C+1, ... -- new
+// images enter exactly one sweep before a check of the running ones: that sweep is their sweep 1,
+// so all slots share the check points for ever.  Per image the arithmetic and the stopping rule are
+// those of a one-image run (cuh:1232-1290).
+
+// put image `slot`'s pixels / codes / wall data / linear guess in place (2-phase native system)
+static int stream_load_slot(deff_ctx *c, int slot, const uint8_t *pix_host)
+{
+    const size_t npix = (size_t)c->W * c->H;
+    uint8_t *dpix = c->pix + (size_t)slot * npix;
+    uint16_t *dcode = c->code + (size_t)slot * c->n_img;
+    HIP_TRY(hipMemcpyAsync(dpix, pix_host, npix, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));        // pix_host is the caller's scratch
+    hipLaunchKernelGGL(k_phase_codes, dim3(grid_for(c->n_img)), dim3(256), 0, c->stream, dpix, c->W, c->ampX, c->ampY,
+                       c->nx, c->ny, c->ny, 0, c->ny, dcode);
+    hipLaunchKernelGGL(k_wall_D_2phase, dim3((c->ny + 255) / 256), dim3(256), 0, c->stream, dpix, c->W, c->ampX, c->ampY,
+                       c->nx, c->ny, c->ny, c->Df, c->Ds, c->Dl + (size_t)slot * c->ny, c->Dr + (size_t)slot * c->ny);
+    hipLaunchKernelGGL(k_init_linear, dim3(grid_for(c->n_img)), dim3(256), 0, c->stream,
+                       c->x[c->cur] + (size_t)slot * c->n_img, c->nx, c->ny, c->CL, c->CR);
+    HIP_TRY(hipGetLastError());
+    c->buf_of[slot] = (uint8_t)c->cur;
+    return DEFF_OK;
+}
+
+static int stream_push_mask(deff_ctx *c, int n_active)
+{
+    bool all = true;
+    for (int k = 0; k < c->nimg; ++k) all = all && c->active_h[k];
+    c->masked = !all && n_active > 0;
+    if (c->masked) {
+        TRY(dev_alloc(&c->active, (size_t)c->nimg));
+        HIP_TRY(hipMemcpyAsync(c->active, c->active_h.data(), (size_t)c->nimg, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return DEFF_OK;
+}
+
+extern "C" int deff_get_slot_field(deff_ctx *c, int slot, double *x)
+{
+    if (!c || !x || slot < 0 || slot >= c->nimg) return fail(DEFF_EINVAL, "bad slot");
+    TRY(use_device(c));
+    HIP_TRY(hipMemcpyAsync(x, c->x[(c->masked || c->in_stream) ? c->buf_of[slot] : c->cur] + (size_t)slot * c->n_img,
+                           sizeof(double) * c->n_img, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DEFF_OK;
+}
+
+extern "C" int deff_solve_stream(deff_ctx *c, int W, int H, int ampX, int ampY, double Ds, double Df, double CL,
+                                 double CR, double omega, double tol, int64_t max_iter, int64_t check_every,
+                                 deff_next_image_fn next, deff_image_done_fn done, void *user)
+{
+    if (!c || !next || !done) return fail(DEFF_EINVAL, "NULL argument");
+    if (check_every < 1) return fail(DEFF_EINVAL, "check_every must be >= 1");
+    if (c->slab) return fail(DEFF_EINVAL, "not for slab contexts");
+    TRY(use_device(c));
+    TRY(image_shape(c, W, H, ampX, ampY));
+    TRY(ensure_walls(c));
+    TRY(dev_alloc(&c->code, c->n));
+    const int B = c->nimg;
+    c->CL = CL; c->CR = CR; c->Ds = Ds; c->Df = Df;
+    build_lut_rows(c, Ds, Df, CL, CR);
+    c->have_image = true; c->have_walls = true; c->have_matfree = true; c->have_explicit = false;
+    c->dict_tried = false; c->have_field = true;
+    HIP_TRY(hipMemsetAsync(c->code, 0, sizeof(uint16_t) * c->n, c->stream));      // empty slots: zero rows
+    HIP_TRY(hipMemsetAsync(c->x[0], 0, sizeof(double) * c->n, c->stream));
+    HIP_TRY(hipMemsetAsync(c->x[1], 0, sizeof(double) * c->n, c->stream));
+    reset_batch_state(c);
+
+    struct Slot { bool live = false; int64_t id = -1, iters = 0, checks = 0; double deffNew = 1, deffOld = 5, change = 100, conv = 0; };
+    std::vector<Slot> S(B);
+    std::vector<uint8_t> pixbuf((size_t)W * H);
+    bool more = true;
+    int n_active = 0;
+    auto refill = [&]() -> int {                       // fill every free slot while images remain
+        for (int k = 0; k < B && more; ++k) {
+            if (S[k].live) continue;
+            int64_t id = -1;
+            const int got = next(user, k, pixbuf.data(), &id);
+            if (got < 0) return fail(DEFF_EINVAL, "image source reported an error");
+            if (got == 0) { more = false; break; }
+            TRY(stream_load_slot(c, k, pixbuf.data()));
+            S[k] = Slot();
+            S[k].live = true; S[k].id = id;
+            c->active_h[k] = 1;
+            ++n_active;
+        }
+        return DEFF_OK;
+    };
+    auto retire = [&](int k, float ms) {
+        deff_result r;
+        r.iters = S[k].iters; r.checks = S[k].checks; r.deff_raw = S[k].deffNew; r.conv = S[k].conv; r.loop_ms = ms;
+        c->active_h[k] = 0;
+        --n_active;
+        done(user, S[k].id, k, &r);                    // the slot's field is still readable (deff_get_slot_field)
+        S[k].live = false;
+    };
+    auto advance = [&](SweepPlan &pl, int64_t nsw) -> int {
+        if (nsw <= 0) return DEFF_OK;
+        enqueue_sweeps(c, pl, nsw);
+        HIP_TRY(hipGetLastError());
+        for (int k = 0; k < B; ++k)
+            if (S[k].live) { S[k].iters += nsw; c->buf_of[k] = (uint8_t)c->cur; }
+        return DEFF_OK;
+    };
+
+    for (int k = 0; k < B; ++k) c->active_h[k] = 0;
+    c->in_stream = true;
+    struct Leave { deff_ctx *c; ~Leave() { c->in_stream = false; } } leave{c};
+    TRY(refill());
+    SweepPlan pl;
+    TRY(plan_sweeps(c, omega, &pl));
+    c->last_launches = 0;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (!(max_iter > 0 && tol < 100.0)) {               // cuh:1232 with change = 100: no sweep at all
+        for (;;) {
+            for (int k = 0; k < B; ++k) if (S[k].live) retire(k, 0.f);
+            if (!more) break;
+            TRY(refill());
+            if (n_active == 0) break;
+        }
+    }
+    // phase of max_iter inside a check interval: live images sit at iters = j*C + 1 after a check
+    while (n_active > 0) {
+        TRY(stream_push_mask(c, n_active));
+        // one sweep (the first of the newly loaded images, sweep j*C + 1 of the others), then the check
+        TRY(advance(pl, 1));
+        TRY(flux_rows(c));
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        HIP_TRY(hipEventSynchronize(c->ev1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        for (int k = 0; k < B; ++k) {
+            if (!S[k].live) continue;
+            Slot &s = S[k];
+            s.deffNew = deff_of_image(c, k);
+            s.change = (s.deffOld - s.deffNew) / (s.deffOld);                     // cuh:1265
+            s.deffOld = s.deffNew;
+            s.conv = s.change;
+            ++s.checks;
+            if (!(tol < fabs(s.change)) || s.iters >= max_iter) retire(k, ms);
+        }
+        if (n_active == 0 && !more) break;
+        // up to the next check: C - 1 sweeps, split where images run into max_iter (they all carry
+        // iters = j*C + 1 with their own j, so each reaches max_iter the same distance after a check)
+        int64_t left = check_every - 1;
+        while (left > 0 && n_active > 0) {
+            int64_t seg = left;
+            for (int k = 0; k < B; ++k)
+                if (S[k].live && max_iter - S[k].iters < seg) seg = max_iter - S[k].iters;
+            if (seg > 0) {
+                TRY(stream_push_mask(c, n_active));
+                TRY(advance(pl, seg));
+                left -= seg;
+            }
+            bool hit = false;
+            for (int k = 0; k < B; ++k)
+                if (S[k].live && S[k].iters >= max_iter) { hit = true; }
+            if (hit) {
+                HIP_TRY(hipEventRecord(c->ev1, c->stream));
+                HIP_TRY(hipEventSynchronize(c->ev1));
+                float ms2 = 0;
+                HIP_TRY(hipEventElapsedTime(&ms2, c->ev0, c->ev1));
+                for (int k = 0; k < B; ++k)
+                    if (S[k].live && S[k].iters >= max_iter) retire(k, ms2);   // MAX_ITER reached between checks, cuh:1232
+            }
+        }
+        TRY(refill());                                 // newcomers start with the sweep that precedes the next check
+    }
+    c->masked = false;
+    reset_batch_state(c);
     return DEFF_OK;
 }
 

@@ -16,7 +16,7 @@
 // --batch-size B (2-phase batch mode): images of equal size are solved B at a time in one stacked
 // context (deff_create_batch) -- each image still stops by its own convergence rule, the numbers are
 // those of the one-at-a-time run, but small images fill the GPU.  Default: as many images as bring
-// the stack to ~4 Mi cells (1 for images that large).
+// the stack to ~16 Mi cells (1 for images that large).
 //
 // --progress file: checkpoint/resume for long batches (the reference keeps all results in memory
 // and loses them if interrupted, doc section 3.6): every finished image appends one line to `file`;
@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -174,38 +175,6 @@ static bool solve_2phase(Session &S, const Image &im, const Options &o, bool sin
     return true;
 }
 
-// BatchSim over a group of equally sized images in ONE stacked context (cuh:1843-2054 per image).
-static bool solve_2phase_group(Session &S, const std::vector<Image> &ims, const Options &o, Row *rows,
-                               std::vector<double> *fields)
-{
-    const int B = (int)ims.size();
-    const int nx = ims[0].W * o.MeshIncreaseX, ny = ims[0].H * o.MeshIncreaseY;
-    if (!S.prepare(nx, ny, B)) return false;
-    std::vector<uint8_t> stack((size_t)B * ims[0].W * ims[0].H);
-    for (int k = 0; k < B; ++k) {
-        std::memcpy(&stack[(size_t)k * ims[0].W * ims[0].H], ims[k].pix.data(), ims[k].pix.size());
-        rows[k].nElements = nx * ny;
-        rows[k].porosity = porosity_of(ims[k]);
-        std::vector<unsigned int> grid = grid_of(ims[k], o, 150);
-        CK(deff_flood_fill(grid.data(), nx, ny, &rows[k].path));
-    }
-    CK(deff_set_image(S.ctx, stack.data(), ims[0].W, ims[0].H, o.MeshIncreaseX, o.MeshIncreaseY));
-    CK(deff_init_linear(S.ctx, o.CLeft, o.CRight));
-    CK(deff_assemble_2phase(S.ctx, o.DCsolid, o.DCfluid, o.CLeft, o.CRight));
-    std::vector<deff_result> res(B);
-    CK(deff_solve_batch(S.ctx, 2.0 / 3.0, o.ConvergeCriteria, o.MAX_ITER, 10000, res.data(), nullptr, nullptr));
-    for (int k = 0; k < B; ++k) {
-        rows[k].deff = res[k].deff_raw / o.DCfluid;                  // cuh:2017
-        rows[k].conv = res[k].conv;
-        rows[k].iters = (long)res[k].iters;
-        rows[k].stages.push_back((long)res[k].iters);
-        rows[k].seconds = res[k].loop_ms / 1000.0 / B;               // the group shares one loop
-        if (o.verbose == 1) std::printf("Number%dDCF = %g, Deff %g\n", k, o.DCfluid, rows[k].deff);
-    }
-    if (fields) { fields->resize((size_t)B * nx * ny); CK(deff_get_field(S.ctx, fields->data())); }
-    return true;
-}
-
 // 3-phase image: FloodFill on pixels > 200, DCG continuation (cuh:1443-1597).
 static bool solve_3phase(Session &S, const Image &im, const Options &o, Row *row, std::vector<double> *field)
 {
@@ -312,6 +281,97 @@ static void write_json(const std::string &path, const Options &o, const std::vec
     std::fclose(f);
 }
 
+// ---- 2-phase batch mode as a stream (deff_solve_stream) -----------------------------------------
+// Every worker keeps the slots of one stacked context full: its image source hands out the next
+// unsolved image index from the shared counter, decodes it, computes porosity / PathFlag, and the
+// solver reports each image as it stops.  An image of a different size ends the worker's current
+// stream (the slots drain) and opens the next one.
+static void progress_append(const std::string &path, int k, const Row &r);
+
+struct Shared {
+    const Options *o;
+    std::vector<Row> *rows;
+    const std::vector<char> *done;
+    std::atomic<int> *next_index;
+    std::atomic<bool> *failed;
+    int count;
+    bool want_field;
+    const std::function<void(int, const double *, int, int)> *emit;
+    const std::string *progress_path;
+    std::function<std::string(int)> name;
+};
+
+struct StreamState {
+    Shared *sh = nullptr;
+    deff_ctx *ctx = nullptr;
+    int W = 0, H = 0;
+    Image pending;                 // image that did not fit the running stream / first image of the next one
+    int pending_k = -1;
+    bool have_pending = false, serve_pending = false;
+};
+
+// fills the row's image statistics and hands the pixels to the solver
+static int stream_emit(StreamState &st, int k, const Image &im, uint8_t *pix, int64_t *id)
+{
+    const Options &o = *st.sh->o;
+    Row &row = (*st.sh->rows)[(size_t)k];
+    row = Row();
+    row.name = st.sh->name(k);
+    const int nx = im.W * o.MeshIncreaseX, ny = im.H * o.MeshIncreaseY;
+    row.nElements = nx * ny;
+    row.porosity = porosity_of(im);
+    std::vector<unsigned int> grid = grid_of(im, o, 150);
+    if (deff_flood_fill(grid.data(), nx, ny, &row.path) != DEFF_OK) { *st.sh->failed = true; return -1; }
+    if (o.verbose == 1) std::printf("Width = %d Height = %d Channel = %d\nPorosity = %g\n", im.W, im.H, im.nChannels, row.porosity);
+    std::memcpy(pix, im.pix.data(), im.pix.size());
+    *id = k;
+    return 1;
+}
+
+static int stream_next(void *user, int /*slot*/, uint8_t *pix, int64_t *id)
+{
+    StreamState &st = *(StreamState *)user;
+    if (st.have_pending) {
+        if (!st.serve_pending) return 0;                         // wrong size for this stream: let it drain
+        st.have_pending = st.serve_pending = false;
+        return stream_emit(st, st.pending_k, st.pending, pix, id);
+    }
+    for (;;) {
+        const int k = st.sh->next_index->fetch_add(1);
+        if (k >= st.sh->count || st.sh->failed->load()) return 0;
+        if ((*st.sh->done)[(size_t)k]) continue;                 // resumed run: already in the progress file
+        Image im;
+        if (!load_image(st.sh->name(k), &im)) { *st.sh->failed = true; return -1; }
+        if (im.W != st.W || im.H != st.H) {
+            st.pending = std::move(im);
+            st.pending_k = k;
+            st.have_pending = true;
+            st.serve_pending = false;
+            return 0;
+        }
+        return stream_emit(st, k, im, pix, id);
+    }
+}
+
+static void stream_done(void *user, int64_t id, int slot, const deff_result *r)
+{
+    StreamState &st = *(StreamState *)user;
+    const Options &o = *st.sh->o;
+    Row &row = (*st.sh->rows)[(size_t)id];
+    row.deff = r->deff_raw / o.DCfluid;                          // cuh:2017
+    row.conv = r->conv;
+    row.iters = (long)r->iters;
+    row.stages.push_back((long)r->iters);
+    row.seconds = r->loop_ms / 1000.0;                           // stream time when the image stopped
+    if (o.verbose == 1) std::printf("Number%dDCF = %g, Deff %g\n", (int)id, o.DCfluid, row.deff);
+    progress_append(*st.sh->progress_path, (int)id, row);
+    if (st.sh->want_field) {
+        const int nx = st.W * o.MeshIncreaseX, ny = st.H * o.MeshIncreaseY;
+        std::vector<double> x((size_t)nx * ny);
+        if (deff_get_slot_field(st.ctx, slot, x.data()) == DEFF_OK) (*st.sh->emit)((int)id, x.data(), nx, ny);
+    }
+}
+
 // One line per finished image: index and every field of its row, doubles as hex floats (exact).
 static void progress_append(const std::string &path, int k, const Row &r)
 {
@@ -390,7 +450,7 @@ int main(int argc, char **argv)
     const int count = o.BatchFlag ? o.NumImg : 1;
     std::vector<Row> rows((size_t)count);
     const bool want_field = o.printCmap == 1 || !field_prefix.empty();
-    auto emit_field = [&](int k, const double *x, int nx, int ny) {
+    const std::function<void(int, const double *, int, int)> emit_field = [&](int k, const double *x, int nx, int ny) {
         if (o.printCmap == 1) {
             char cm[32];
             std::snprintf(cm, sizeof cm, "CMAP_%05d.csv", k);        // batch naming, cuh:2387
@@ -402,82 +462,93 @@ int main(int argc, char **argv)
             if (FILE *f = std::fopen(fn, "wb")) { std::fwrite(x, sizeof(double), (size_t)nx * ny, f); std::fclose(f); }
         }
     };
-    auto image_name = [&](int k) {
+    const std::function<std::string(int)> image_name = [&](int k) {
         char numbered[32];
         std::snprintf(numbered, sizeof numbered, "%05d.jpg", k);     // cuh:1876
         return o.BatchFlag ? std::string(numbered) : o.inputFilename;
     };
 
-    // Work items = runs of `group` consecutive images (2-phase batch mode: solved together in one
-    // stacked context when they have the same size).  One host thread per device takes items from
-    // a shared counter -- whole images per GPU, no communication -- and JPEG
-    // decoding, flood fill and uploads of one item overlap the other devices' solves.  Rows land in
-    // the table by image index, so the output does not depend on the number of devices.
-    int group = 1;
-    if (o.BatchFlag && o.nPhase == 2) {
-        group = batch_size;
-        if (group <= 0) {
-            Image first;
-            if (!load_image(image_name(0), &first)) return 1;
-            const long long cells = (long long)first.W * o.MeshIncreaseX * first.H * o.MeshIncreaseY;
-            group = (int)std::max<long long>(1, (4ll << 20) / std::max<long long>(1, cells));
-        }
-    }
+    // Work distribution: one host thread per device takes image indices from a shared counter --
+    // whole images per GPU, no communication; JPEG decoding, flood fill and uploads
+    // of one worker overlap the other devices' solves.  Rows land in the table by image index, so
+    // the output does not depend on the number of devices or slots.
     std::vector<char> done((size_t)count, 0);
     progress_load(progress_path, rows, done);
     for (int k = 0; k < count; ++k)
         if (done[(size_t)k]) rows[(size_t)k].name = image_name(k);
-    const int items = (count + group - 1) / group;
-    std::atomic<int> next_item{0};
+    std::atomic<int> next_index{0};
     std::atomic<bool> failed{false};
+
+    // ---- 2-phase batch mode: streaming slots (deff_solve_stream) --------------------------------
+    Shared shared{&o, &rows, &done, &next_index, &failed, count, want_field, &emit_field, &progress_path, image_name};
+    auto stream_worker = [&](int dev) {
+        StreamState st;
+        st.sh = &shared;
+        for (;;) {
+            if (!st.have_pending) {                              // first image of the next stream fixes its size
+                int k;
+                do { k = next_index.fetch_add(1); } while (k < count && done[(size_t)k]);
+                if (k >= count || failed.load()) return;
+                if (!load_image(image_name(k), &st.pending)) { failed = true; return; }
+                st.pending_k = k;
+                st.have_pending = true;
+            }
+            st.W = st.pending.W; st.H = st.pending.H;
+            st.serve_pending = true;
+            const int nx = st.W * o.MeshIncreaseX, ny = st.H * o.MeshIncreaseY;
+            // default: enough slots for a stack of ~16 Mi cells (a 128^2 image is 1 strip x few chunks: the
+            // chip needs about a thousand of them in flight)
+            int slots = batch_size > 0 ? batch_size : (int)std::max<long long>(1, (16ll << 20) / ((long long)nx * ny));
+            slots = std::min(slots, 4096);
+            if (deff_create_batch(dev, nx, ny, slots, &st.ctx) != DEFF_OK) {
+                std::fprintf(stderr, "deff2d: %s\n", deff_last_error());
+                failed = true;
+                return;
+            }
+            const int rc = deff_solve_stream(st.ctx, st.W, st.H, o.MeshIncreaseX, o.MeshIncreaseY, o.DCsolid, o.DCfluid,
+                                             o.CLeft, o.CRight, 2.0 / 3.0, o.ConvergeCriteria, o.MAX_ITER, 10000, stream_next,
+                                             stream_done, &st);
+            deff_destroy(st.ctx);
+            st.ctx = nullptr;
+            if (rc != DEFF_OK) {
+                std::fprintf(stderr, "deff2d: %s\n", deff_last_error());
+                failed = true;
+                return;
+            }
+            if (!st.have_pending) return;                        // the source ran dry (no odd-sized image waiting)
+        }
+    };
+
+    // ---- every other mode: one image at a time ----------------------------------------------------
     auto worker = [&](int dev) {
         Session S;
         S.device = dev;
         for (;;) {
-            const int w = next_item.fetch_add(1);
-            if (w >= items || failed.load()) break;
-            const int k0 = w * group, k1 = std::min(count, k0 + group);
-            bool all_done = true;
-            for (int k = k0; k < k1; ++k) all_done = all_done && done[(size_t)k];
-            if (all_done) continue;                              // resumed run: this item is already in the progress file
-            std::vector<Image> ims((size_t)(k1 - k0));
-            for (int k = k0; k < k1; ++k) {
-                if (!load_image(image_name(k), &ims[(size_t)(k - k0)])) { failed = true; return; }
-                if (o.verbose == 1)
-                    std::printf("Width = %d Height = %d Channel = %d\n", ims[(size_t)(k - k0)].W, ims[(size_t)(k - k0)].H,
-                                ims[(size_t)(k - k0)].nChannels);
-            }
-            for (int k = k0; k < k1;) {
-                // maximal run of equally sized images starting at k
-                int e = k + 1;
-                while (e < k1 && ims[(size_t)(e - k0)].W == ims[(size_t)(k - k0)].W && ims[(size_t)(e - k0)].H == ims[(size_t)(k - k0)].H) ++e;
-                const Image &im0 = ims[(size_t)(k - k0)];
-                const int nx = im0.W * o.MeshIncreaseX, ny = im0.H * o.MeshIncreaseY;
-                for (int q = k; q < e; ++q) { rows[(size_t)q] = Row(); rows[(size_t)q].name = image_name(q); }   // also drops resumed leftovers
-                std::vector<double> fields;
-                bool ok;
-                if (e - k > 1) {
-                    std::vector<Image> run(ims.begin() + (k - k0), ims.begin() + (e - k0));
-                    ok = solve_2phase_group(S, run, o, &rows[(size_t)k], want_field ? &fields : nullptr);
-                } else if (o.nPhase == 2) {
-                    ok = solve_2phase(S, im0, o, !o.BatchFlag, &rows[(size_t)k], want_field ? &fields : nullptr);
-                    if (ok && o.verbose == 1) std::printf("Porosity = %g\n", rows[(size_t)k].porosity);
-                } else {
-                    ok = solve_3phase(S, im0, o, &rows[(size_t)k], want_field ? &fields : nullptr);
-                }
-                if (!ok) { failed = true; return; }
-                for (int q = k; q < e; ++q) progress_append(progress_path, q, rows[(size_t)q]);
-                if (want_field)
-                    for (int q = k; q < e; ++q) emit_field(q, fields.data() + (size_t)(q - k) * nx * ny, nx, ny);
-                k = e;
-            }
+            const int k = next_index.fetch_add(1);
+            if (k >= count || failed.load()) break;
+            if (done[(size_t)k]) continue;                       // resumed run
+            Image im;
+            if (!load_image(image_name(k), &im)) { failed = true; return; }
+            if (o.verbose == 1) std::printf("Width = %d Height = %d Channel = %d\n", im.W, im.H, im.nChannels);
+            const int nx = im.W * o.MeshIncreaseX, ny = im.H * o.MeshIncreaseY;
+            rows[(size_t)k] = Row();
+            rows[(size_t)k].name = image_name(k);
+            std::vector<double> field;
+            const bool ok = (o.nPhase == 2) ? solve_2phase(S, im, o, !o.BatchFlag, &rows[(size_t)k], want_field ? &field : nullptr)
+                                            : solve_3phase(S, im, o, &rows[(size_t)k], want_field ? &field : nullptr);
+            if (!ok) { failed = true; return; }
+            if (o.verbose == 1 && o.nPhase == 2) std::printf("Porosity = %g\n", rows[(size_t)k].porosity);
+            progress_append(progress_path, k, rows[(size_t)k]);
+            if (want_field) emit_field(k, field.data(), nx, ny);
         }
     };
-    if (devices.size() <= 1 || items <= 1) {
-        worker(devices.empty() ? device : devices[0]);
+    const bool streaming = o.BatchFlag && o.nPhase == 2;
+    auto run = [&](int dev) { if (streaming) stream_worker(dev); else worker(dev); };
+    if (devices.size() <= 1 || count <= 1) {
+        run(devices.empty() ? device : devices[0]);
     } else {
         std::vector<std::thread> pool;
-        for (int dev : devices) pool.emplace_back(worker, dev);
+        for (int dev : devices) pool.emplace_back(run, dev);
         for (std::thread &t : pool) t.join();
     }
     if (failed.load()) return 1;

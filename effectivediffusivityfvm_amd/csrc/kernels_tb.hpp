@@ -102,19 +102,29 @@ __device__ __forceinline__ double tb_cell(const double *lut, unsigned off, doubl
 template <int T, bool GUARD, bool WALL>
 __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__restrict__ code,
                                          const double *__restrict__ x, double *__restrict__ xnew, int nx,
-                                         int ny, int row_lo, int own_hi, int tx, int ry0, int LY, int lane,
-                                         double omw)
+                                         int ny, int row_lo, int own_hi, int tx, int ntx, int shift, int ry0, int LY,
+                                         int lane, double omw)
 {
     // column halo rounded up to even so that odd T keeps the 16-B alignment of a lane's pair
     constexpr int HW = (T + 1) & ~1;
     constexpr int WOUT = TB_COLS - 2 * HW;
-    const int cx0 = tx * WOUT;                     // first output column of the strip
-    const int col = cx0 - HW + 2 * lane;           // this lane's first column (even)
-    const bool in_x = (col >= 0) && (col < nx);    // nx even => col+1 < nx too
+    // Strip tx reads columns [tx*WOUT, tx*WOUT + 128) and owns the outputs [out_lo, out_hi): its
+    // window minus HW stale columns on each side that borders another strip -- a side that is a
+    // wall of the mesh needs no halo, so the first strip starts at column 0 and an image of up to
+    // 128 columns is a single strip with nothing recomputed.
+    // (shift = HW selects the older placement with a halo also outside the first column; kept as
+    // a tuning switch so that the two can be compared inside one process.)
+    const int col = tx * WOUT - shift + 2 * lane;  // this lane's first column (even)
+    const bool in_x = col >= 0 && col < nx;        // nx even => col+1 < nx too
+    const int out_lo = (tx == 0) ? 0 : tx * WOUT - shift + HW;
+    const int out_hi = (tx == ntx - 1) ? nx : tx * WOUT - shift + TB_COLS - HW;
     const int row_hi = row_lo + ny;
     const int ry1 = min(ry0 + LY, own_hi);
-    const int r_begin = ry0 - T, r_end = ry1 + T;  // input rows [r_begin, r_end)
-    const bool st_x = in_x && (col >= cx0) && (col < cx0 + WOUT);
+    // input rows [r_begin, r_end): T rows of halo above and below the chunk, except that nothing
+    // lies above the first row of the mesh (the steps for rows below the last one still run: they
+    // drain the pipeline)
+    const int r_begin = max(ry0 - T, row_lo), r_end = ry1 + T;
+    const bool st_x = in_x && (col >= out_lo) && (col < out_hi);
     const double2 zero = make_double2(0.0, 0.0);
 
     double2 w[T][3];                               // w[t]: 3 newest rows of sweep t
@@ -206,8 +216,8 @@ __global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restri
                                                           int own_h, int cpi,
                                                           const uint8_t *__restrict__ active,
                                                           int LY, int ntx, int nbt, int gy, int flip,
-                                                          int xmajor, int allb, int nrows, double omw,
-                                                          unsigned long long *__restrict__ stamps)
+                                                          int xmajor, int allb, int nrows, int shift,
+                                                          double omw, unsigned long long *__restrict__ stamps)
 {
     static_assert(T >= 1 && T <= 8 && CPL == 2, "unsupported T / cells per lane");
     __shared__ double lut[LUT_DOUBLES];
@@ -244,9 +254,9 @@ __global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restri
         // b is read only where it can be non-zero: strips holding a wall column, or everywhere for a
         // harvested dictionary whose right-hand side is not confined to the walls
         if (allb || tx == 0 || tx == ntx - 1)
-            tb_strip<T, GUARD, true>(lut, code, x, xnew, nx, ny, row_lo, own0 + own_h, tx, ry0, LY, lane, omw);
+            tb_strip<T, GUARD, true>(lut, code, x, xnew, nx, ny, row_lo, own0 + own_h, tx, ntx, shift, ry0, LY, lane, omw);
         else
-            tb_strip<T, GUARD, false>(lut, code, x, xnew, nx, ny, row_lo, own0 + own_h, tx, ry0, LY, lane, omw);
+            tb_strip<T, GUARD, false>(lut, code, x, xnew, nx, ny, row_lo, own0 + own_h, tx, ntx, shift, ry0, LY, lane, omw);
         if (stamps && lane == 0) {
             stamps[2 * (size_t)wt] = t_begin;
             stamps[2 * (size_t)wt + 1] = wall_clock64();

@@ -15,7 +15,7 @@ OMEGA_REFERENCE = 2.0 / 3.0     # updateX_SOR, Deff2D.cuh:72
 
 
 class SolveResult:
-    __slots__ = ("iters", "checks", "deff_raw", "conv", "loop_ms", "MFL", "MFR")
+    __slots__ = ("iters", "checks", "deff_raw", "conv", "loop_ms", "MFL", "MFR", "field")
 
     def __repr__(self):
         return (f"SolveResult(iters={self.iters}, checks={self.checks}, deff_raw={self.deff_raw!r}, "
@@ -151,6 +151,53 @@ class Solver:
             out.MFR = MFR[k * self.ny:(k + 1) * self.ny]
             outs.append(out)
         return outs[0] if self.nimg == 1 else outs
+
+    def solve_stream(self, images, Ds, Df, CL, CR, tol, max_iter, omega=OMEGA_REFERENCE, check_every=10000,
+                     want_fields=False, ampX=1, ampY=1):
+        """Dataset generation: `images` is any iterable of uint8 (H, W) arrays of one size; the nimg
+        slots of this context are kept full (a finished image's slot is refilled with the next one).
+        Returns a list with one SolveResult per image, in input order (plus .field when want_fields)."""
+        it = iter(images)
+        H, W = self.ny // ampY, self.nx // ampX
+        results = {}
+        counter = [0]
+        errors = []
+
+        def _next(_user, _slot, pix_ptr, id_ptr):
+            try:
+                img = next(it)
+            except StopIteration:
+                return 0
+            except Exception as e:          # noqa: BLE001 - reported to the C side as an error code
+                errors.append(e)
+                return -1
+            a = np.ascontiguousarray(img, dtype=np.uint8)
+            if a.shape != (H, W):
+                errors.append(ValueError(f"image {counter[0]} is {a.shape}, expected {(H, W)}"))
+                return -1
+            C.memmove(pix_ptr, a.ctypes.data, a.size)
+            id_ptr[0] = counter[0]
+            counter[0] += 1
+            return 1
+
+        def _done(_user, image_id, slot, res_ptr):
+            r = res_ptr[0]
+            out = SolveResult()
+            out.iters, out.checks, out.deff_raw, out.conv, out.loop_ms = r.iters, r.checks, r.deff_raw, r.conv, r.loop_ms
+            out.MFL = out.MFR = None
+            if want_fields:
+                x = np.empty((self.ny, self.nx), dtype=np.float64)
+                check(self._L.deff_get_slot_field(self._ctx, slot, x))
+                out.field = x
+            results[int(image_id)] = out
+
+        nxt, dn = _capi.NEXT_IMAGE_FN(_next), _capi.IMAGE_DONE_FN(_done)
+        rc = self._L.deff_solve_stream(self._ctx, W, H, ampX, ampY, Ds, Df, CL, CR, omega, tol, int(max_iter),
+                                       int(check_every), nxt, dn, None)
+        if errors:
+            raise errors[0]
+        check(rc)
+        return [results[k] for k in range(counter[0])]
 
     def sweeps(self, n, omega=OMEGA_REFERENCE):
         ms = C.c_float()

@@ -128,6 +128,19 @@ int deff_solve(deff_ctx *ctx, double omega, double tol, int64_t max_iter, int64_
  * end, its field is frozen) while the others continue; MFL/MFR hold nimg*ny values */
 int deff_solve_batch(deff_ctx *ctx, double omega, double tol, int64_t max_iter, int64_t check_every,
                      deff_result *out, double *MFL, double *MFR);
+/* streaming batch (dataset generation): the nimg slots of a batch context are kept full -- when a
+ * slot's image stops (its own rule), its result is reported and the slot is refilled with the next
+ * image, which enters one sweep before a check of the running ones so that every image keeps the
+ * reference's schedule (checks after its own sweeps 1, C+1, 2C+1, ...).  2-phase native system.
+ *   next(user, slot, pix, &image_id) fills W*H bytes: 1 = image provided, 0 = no more, <0 = error
+ *   done(user, image_id, slot, result): called once per image; deff_get_slot_field(ctx, slot, x)
+ *   may be called from inside it to fetch the image's final field */
+typedef int (*deff_next_image_fn)(void *user, int slot, uint8_t *pix, int64_t *image_id);
+typedef void (*deff_image_done_fn)(void *user, int64_t image_id, int slot, const deff_result *res);
+int deff_solve_stream(deff_ctx *ctx, int W, int H, int ampX, int ampY, double Ds, double Df, double CL,
+                      double CR, double omega, double tol, int64_t max_iter, int64_t check_every,
+                      deff_next_image_fn next, deff_image_done_fn done, void *user);
+int deff_get_slot_field(deff_ctx *ctx, int slot, double *x /* nx*ny */);
 /* optional observer called on the host after every convergence check with
  * (iter of the checked sweep, Deff, signed change): what the reference prints under
  * Verbose (cuh:1267-1271).  NULL removes it. */

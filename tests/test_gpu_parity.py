@@ -157,6 +157,7 @@ def test_temporal_blocking_vs_oracle(pkg, oracle, shape, LY, T):
     with pkg.Solver(nx, ny, kernel="matfree_tb") as s:
         s.set_tuning("tb_T", T)
         s.set_tuning("tb_LY", LY)
+        s.set_tuning("tb_wall_halo", (nx + ny + T) % 3)        # all three strip placements get exercised
         s.set_image(pix)
         s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
         s.set_field(x0)
@@ -289,6 +290,32 @@ def test_batch_solve_each_image_stops_by_its_own_rule(pkg, oracle, kernel):
         assert (res2[k].iters, res2[k].deff_raw, res2[k].conv) == (it2, deff2, conv2)
         assert_field(got2[k], x2)
     assert len(its) >= 3, its                # the batch really did split up
+
+
+@pytest.mark.parametrize("slots,max_iter", [(3, 5000), (4, 730), (2, 1), (16, 5000)])
+def test_streaming_batch_refills_slots(pkg, oracle, slots, max_iter):
+    """11 images through `slots` slots: finished images are replaced on the fly, and every image
+    still reports exactly what a one-image run of the reference loop gives (sweep count, Deff,
+    conv, field), including images that run into MAX_ITER between checks."""
+    nx, ny = 64, 48
+    rng = np.random.default_rng(2024)
+    imgs = [rand_mask(rng, nx, ny, p) for p in (0.3, 0.5, 0.7, 0.9, 0.5, 0.2, 0.8, 0.6, 0.4, 0.55, 0.35)]
+    imgs[3][:] = 255
+    imgs[3][:10, :] = 0                      # parallel stripes: stops at its second check
+    with pkg.Solver(nx, ny, nimg=slots) as s:
+        res = s.solve_stream(imgs, 1e-2, 1.0, 0.0, 1.0, 2e-3, max_iter, check_every=100, want_fields=True)
+    assert len(res) == len(imgs)
+    counts = set()
+    for k, pix in enumerate(imgs):
+        D = oracle.fill_D_2phase(pix, 1.0, 1e-2)
+        A, b = oracle.discretize(D, 0.0, 1.0)
+        it, deff, conv, x, _, _ = oracle.jacobi(A, b, oracle.linear_guess(nx, ny, 0.0, 1.0), D, 0.0, 1.0, 2e-3,
+                                                max_iter, check_every=100)
+        counts.add(it)
+        assert (res[k].iters, res[k].deff_raw, res[k].conv) == (it, deff, conv), (k, res[k], it, deff, conv)
+        assert_field(res[k].field, x)
+    if max_iter == 5000:
+        assert len(counts) >= 4
 
 
 def test_batch_synthetic_first_check_at_1024(pkg, oracle, recorded):
