@@ -15,7 +15,10 @@ EXE = os.path.join(ROOT, "effectivediffusivityfvm_amd", "deff2d")
 
 @pytest.fixture(scope="module")
 def built():
-    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "effectivediffusivityfvm_amd", "csrc")], check=True)
+    # build only what is missing: libdeff_amd.so may already be loaded by this process
+    pkg_dir = os.path.join(ROOT, "effectivediffusivityfvm_amd")
+    if not (os.path.exists(os.path.join(pkg_dir, "libdeff_amd.so")) and os.path.exists(EXE)):
+        subprocess.run(["make", "-s", "-C", os.path.join(pkg_dir, "csrc")], check=True)
     assert os.access(EXE, os.X_OK)
     return EXE
 
