@@ -243,6 +243,9 @@ def main():
             # this kernel never materialises A: its own compulsory traffic is x 8 + code 2 read, xNew 8
             # written per cell per LAUNCH (a temporally blocked launch does sweeps_per_launch sweeps on it)
             own = 18.0 * cells
+            if kernel_used == "matfree_tb":
+                out["roofline"]["limiter"] = ("not HBM: FP64 VALU issue ~55 % + LDS row lookups ~43 % busy, "
+                                              "profiles/r01d_tb_sq_counters.json")
             out["roofline"]["own_model"] = {
                 "bytes_per_launch": own,
                 "achieved": own / launch_s / 1e9,
