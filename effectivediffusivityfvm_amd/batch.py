@@ -63,18 +63,36 @@ def run_batch(solver, load_image, num_images, Ds, Df, CL, CR, tol, max_iter, ran
               device=None, path_flag=None):
     """Solve images rank, rank+world, ... and gather the table on rank 0.
 
+    solver: a Solver for one image at a time, or a batch Solver (nimg > 1) whose slots are then kept
+    full with this rank's images (streaming, every image still stops by its own rule).
     load_image(k) -> uint8 (H, W) pixels of image k (stb-decoded JPEG or synthetic).
     path_flag: callable(pix) -> bool for the PathFlag column (path_flag_2phase), None = -1.
     Returns the (num_images, 9) table on rank 0, None elsewhere.
     """
     mine = shard(num_images, rank, world)
     rows = np.zeros((len(mine), len(COLUMNS)))
-    for slot, k in enumerate(mine):
-        pix = load_image(k)
-        porosity = float(np.count_nonzero(pix < 150)) / pix.size            # calcPorosity cuh:383-408
-        deff, conv, iters, ms = solve_image(solver, pix, Ds, Df, CL, CR, tol, max_iter)
-        path = path_flag(pix) if path_flag is not None else -1.0
-        rows[slot] = (k, porosity, float(path), deff, ms / 1000.0, pix.size, conv, Ds, Df)
+    if hasattr(solver, "solve_stream") and getattr(solver, "nimg", 1) > 1:
+        # a batch context: keep its slots full with this rank's images (deff_solve_stream)
+        stats = []
+
+        def images():
+            for k in mine:
+                pix = load_image(k)
+                stats.append((float(np.count_nonzero(pix < 150)) / pix.size,        # calcPorosity cuh:383-408
+                              float(path_flag(pix)) if path_flag is not None else -1.0, pix.size))
+                yield pix
+
+        res = solver.solve_stream(images(), Ds, Df, CL, CR, tol, max_iter)
+        for slot, (k, r) in enumerate(zip(mine, res)):
+            porosity, path, size = stats[slot]
+            rows[slot] = (k, porosity, path, r.deff_raw / Df, r.loop_ms / 1000.0, size, r.conv, Ds, Df)
+    else:
+        for slot, k in enumerate(mine):
+            pix = load_image(k)
+            porosity = float(np.count_nonzero(pix < 150)) / pix.size            # calcPorosity cuh:383-408
+            deff, conv, iters, ms = solve_image(solver, pix, Ds, Df, CL, CR, tol, max_iter)
+            path = path_flag(pix) if path_flag is not None else -1.0
+            rows[slot] = (k, porosity, float(path), deff, ms / 1000.0, pix.size, conv, Ds, Df)
     if world == 1 or dist is None:
         return rows
     import torch

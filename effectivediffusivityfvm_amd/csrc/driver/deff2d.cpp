@@ -225,6 +225,61 @@ static bool solve_3phase(Session &S, const Image &im, const Options &o, Row *row
     return true;
 }
 
+// BatchSim3Phase over a group of equally sized images in ONE stacked context (cuh:2056-2419 per
+// image).  All images go through a continuation stage together -- each stops by its own rule
+// inside the stage (deff_solve_batch) -- and the next stage starts when the last one is done; the
+// stage systems are harvested into a row dictionary and swept by the temporally blocked kernel.
+static bool solve_3phase_group(Session &S, const std::vector<Image> &ims, const Options &o, Row *rows,
+                               std::vector<double> *fields)
+{
+    const int B = (int)ims.size();
+    const int nx = ims[0].W * o.MeshIncreaseX, ny = ims[0].H * o.MeshIncreaseY;
+    if (!S.prepare(nx, ny, B)) return false;
+    const size_t npix = (size_t)ims[0].W * ims[0].H, ncell = (size_t)nx * ny;
+    std::vector<uint8_t> stack(npix * B);
+    std::vector<unsigned int> grid(ncell * B);
+    const double DCF = o.DCfluid, DCG = o.DCgas, DCS = o.DCsolid;
+    for (int k = 0; k < B; ++k) {
+        std::memcpy(&stack[npix * k], ims[k].pix.data(), npix);
+        rows[k].nElements = nx * ny;
+        std::vector<unsigned int> g = grid_of(ims[k], o, 200);
+        CK(deff_flood_fill(g.data(), nx, ny, &rows[k].path));
+        std::memcpy(&grid[ncell * k], g.data(), sizeof(unsigned int) * ncell);
+        const double total = (double)ncell;                          // calcFracts3D, cuh:411-448
+        double s = 0, l = 0;
+        for (int i = 0; i < ny; ++i)
+            for (int j = 0; j < nx; ++j) {
+                const uint8_t v = ims[k].pix[(size_t)(i / o.MeshIncreaseY) * ims[k].W + j / o.MeshIncreaseX];
+                const double D = v > 200 ? DCS : (v < 50 ? DCG : DCF);
+                if (D == DCS) s += 1.0 / total;
+                else if (D == DCF) l += 1.0 / total;
+            }
+        rows[k].SVF = s; rows[k].LVF = l;
+    }
+    CK(deff_set_image(S.ctx, stack.data(), ims[0].W, ims[0].H, o.MeshIncreaseX, o.MeshIncreaseY));
+    CK(deff_init_linear(S.ctx, o.CLeft, o.CRight));
+    std::vector<deff_result> res(B);
+    int stage_no = 1;
+    for (double g = 10; g < DCG; g *= 10, ++stage_no) {              // JacobiGPUPreCond stages, cuh:2184-2326
+        if (o.verbose == 1) std::printf("Pre-Cond Stage %d: DCG = %1.3e\n", stage_no, g);
+        CK(deff_assemble_3phase(S.ctx, DCS, DCF, g, grid.data(), o.CLeft, o.CRight));
+        CK(deff_solve_batch(S.ctx, 2.0 / 3.0, o.ConvergeCriteria * 10, 1000000, 10000, res.data(), nullptr, nullptr));
+        for (int k = 0; k < B; ++k) rows[k].stages.push_back((long)res[k].iters);
+    }
+    CK(deff_assemble_3phase(S.ctx, DCS, DCF, DCG, grid.data(), o.CLeft, o.CRight));
+    CK(deff_solve_batch(S.ctx, 2.0 / 3.0, o.ConvergeCriteria, o.MAX_ITER, 10000, res.data(), nullptr, nullptr));
+    for (int k = 0; k < B; ++k) {
+        rows[k].stages.push_back((long)res[k].iters);
+        rows[k].iters = (long)res[k].iters;
+        rows[k].deff = res[k].deff_raw / DCF;                        // cuh:2370
+        rows[k].conv = res[k].conv;
+        rows[k].seconds = res[k].loop_ms / 1000.0 / B;               // final stage only (cuh:1147), shared by the group
+        if (o.verbose == 1) std::printf("Number%dDCF = %g, Deff %g\n", k, DCF, rows[k].deff);
+    }
+    if (fields) { fields->resize(ncell * B); CK(deff_get_field(S.ctx, fields->data())); }
+    return true;
+}
+
 static void write_cmap(const std::string &name, const std::vector<double> &x, int nx, int ny)   // createCMAP, cuh:497-524
 {
     FILE *f = std::fopen(name.c_str(), "w+");
@@ -520,6 +575,45 @@ int main(int argc, char **argv)
     };
 
     // ---- every other mode: one image at a time ----------------------------------------------------
+    // 3-phase batch mode: work items are runs of `group3` consecutive images, solved together
+    // when equally sized
+    std::atomic<int> next_item{0};
+    auto worker3 = [&](int dev) {
+        Session S;
+        S.device = dev;
+        int group3 = batch_size;
+        for (;;) {
+            if (group3 <= 0) {                                   // default: a stack of ~16 Mi cells
+                Image first;
+                if (!load_image(image_name(0), &first)) { failed = true; return; }
+                group3 = (int)std::max<long long>(1, std::min<long long>(4096, (16ll << 20) /
+                          ((long long)first.W * o.MeshIncreaseX * first.H * o.MeshIncreaseY)));
+            }
+            const int w = next_item.fetch_add(1);
+            const int k0 = w * group3, k1 = std::min(count, k0 + group3);
+            if (k0 >= count || failed.load()) break;
+            bool all_done = true;
+            for (int k = k0; k < k1; ++k) all_done = all_done && done[(size_t)k];
+            if (all_done) continue;
+            std::vector<Image> ims((size_t)(k1 - k0));
+            for (int k = k0; k < k1; ++k)
+                if (!load_image(image_name(k), &ims[(size_t)(k - k0)])) { failed = true; return; }
+            for (int k = k0; k < k1;) {
+                int e = k + 1;
+                while (e < k1 && ims[(size_t)(e - k0)].W == ims[(size_t)(k - k0)].W && ims[(size_t)(e - k0)].H == ims[(size_t)(k - k0)].H) ++e;
+                const int nx = ims[(size_t)(k - k0)].W * o.MeshIncreaseX, ny = ims[(size_t)(k - k0)].H * o.MeshIncreaseY;
+                for (int q = k; q < e; ++q) { rows[(size_t)q] = Row(); rows[(size_t)q].name = image_name(q); }
+                std::vector<Image> run(ims.begin() + (k - k0), ims.begin() + (e - k0));
+                std::vector<double> fields;
+                if (!solve_3phase_group(S, run, o, &rows[(size_t)k], want_field ? &fields : nullptr)) { failed = true; return; }
+                for (int q = k; q < e; ++q) {
+                    progress_append(progress_path, q, rows[(size_t)q]);
+                    if (want_field) emit_field(q, fields.data() + (size_t)(q - k) * nx * ny, nx, ny);
+                }
+                k = e;
+            }
+        }
+    };
     auto worker = [&](int dev) {
         Session S;
         S.device = dev;
@@ -543,7 +637,8 @@ int main(int argc, char **argv)
         }
     };
     const bool streaming = o.BatchFlag && o.nPhase == 2;
-    auto run = [&](int dev) { if (streaming) stream_worker(dev); else worker(dev); };
+    const bool grouped3 = o.BatchFlag && o.nPhase == 3;
+    auto run = [&](int dev) { if (streaming) stream_worker(dev); else if (grouped3) worker3(dev); else worker(dev); };
     if (devices.size() <= 1 || count <= 1) {
         run(devices.empty() ? device : devices[0]);
     } else {

@@ -197,3 +197,37 @@ def test_driver_batch_groups_images(built, tmp_path, oracle):
             assert res["image"] == f"{k:05d}.jpg"
             assert (res["iterations"], res["Deff"], res["converge"]) == (it, deff, conv), (bs, k)
             assert res["PathFlag"] == int(oracle.floodfill((pixs[k] > 150).astype(np.uint32))[1])
+
+
+@pytest.mark.gpu
+def test_driver_3phase_batch_groups(built, tmp_path, oracle):
+    """RunBatch with 3 phases: equally sized images go through the DCG continuation together in one
+    stacked context; every image's stage iteration counts, Deff and conv equal the oracle's one-image flow."""
+    from PIL import Image
+    import effectivediffusivityfvm_amd as pkg
+    rng = np.random.default_rng(77)
+    pixs = []
+    for k in range(5):
+        f = np.kron(rng.random((6, 8)), np.ones((8, 8)))
+        a = np.where(f < 0.3, 0, np.where(f < 0.65, 150, 255)).astype(np.uint8)
+        Image.fromarray(a).save(tmp_path / f"{k:05d}.jpg", quality=100)
+        pixs.append(pkg.load_jpeg_gray(tmp_path / f"{k:05d}.jpg"))
+    _write_input(tmp_path / "input.txt", Phases=3, Ds=0, Df=1, Dg=2500, MeshAmpX=1, MeshAmpY=1, CR=1, CL=0,
+                 OutputName="out.csv", printCMap=0, Convergence="1e-4", MaxIter="3e5", Verbose=0, RunBatch=1,
+                 NumImages=5)
+    out = {}
+    for bs in (3, 1):
+        r = subprocess.run([EXE, "input.txt", "--json", f"res{bs}.json", "--batch-size", str(bs)], cwd=tmp_path,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr + r.stdout
+        out[bs] = json.load(open(tmp_path / f"res{bs}.json"))["results"]
+    for k in range(5):
+        with np.errstate(all="ignore"):
+            want = oracle.solve_3phase(pixs[k], 0.0, 1.0, 2500.0, 0.0, 1.0, 1e-4, 300000)
+        for bs in (3, 1):
+            res = out[bs][k]
+            assert res["stage_iterations"] == want["stage_sweeps"], (bs, k)
+            assert res["Deff"] == want["deff"] and res["converge"] == want["conv"]
+            assert res["SVF"] == want["SVF"] and res["LVF"] == want["LVF"] and res["PathFlag"] == int(want["path"])
+    rows = open(tmp_path / "out.csv").read().splitlines()
+    assert rows[0] == "imgNum,SVF,LVF,PathFlag,Deff,Time,nElements,converge,ds,df,dg" and rows[1].startswith("0,")

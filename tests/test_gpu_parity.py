@@ -318,6 +318,27 @@ def test_streaming_batch_refills_slots(pkg, oracle, slots, max_iter):
         assert len(counts) >= 4
 
 
+def test_run_batch_table_streaming_equals_one_at_a_time(pkg, oracle):
+    """batch.run_batch (BatchSim's NumImg x 9 table) through a streaming batch context and through a
+    one-image context: same table, and its Deff column equals the oracle's."""
+    from effectivediffusivityfvm_amd import batch
+    nx, ny, N = 48, 40, 9
+
+    def load(k):
+        return oracle.synth_mask(nx, ny, 999, k)
+
+    with pkg.Solver(nx, ny, nimg=4) as s4, pkg.Solver(nx, ny) as s1:
+        t4 = batch.run_batch(s4, load, N, 1e-2, 2.0, 0.0, 1.0, 1e-3, 20000, path_flag=batch.path_flag_2phase)
+        t1 = batch.run_batch(s1, load, N, 1e-2, 2.0, 0.0, 1.0, 1e-3, 20000, path_flag=batch.path_flag_2phase)
+    keep = [i for i, c in enumerate(batch.COLUMNS) if c != "Time"]
+    assert np.array_equal(t4[:, keep], t1[:, keep])
+    for k in range(N):
+        D = oracle.fill_D_2phase(load(k), 2.0, 1e-2)
+        A, b = oracle.discretize(D, 0.0, 1.0)
+        it, deff, conv, _, _, _ = oracle.jacobi(A, b, oracle.linear_guess(nx, ny, 0.0, 1.0), D, 0.0, 1.0, 1e-3, 20000)
+        assert t4[k, 3] == deff / 2.0 and t4[k, 6] == conv and t4[k, 0] == k
+
+
 def test_batch_synthetic_first_check_at_1024(pkg, oracle, recorded):
     """4 stacked 1024^2 synthetic images = images 0..3 of the generator; image 0 must give the
     reference's recorded first-check Deff, the others the oracle's."""
