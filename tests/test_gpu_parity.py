@@ -712,6 +712,62 @@ def test_mirror_symmetry_at_1024(pkg):
     assert rel_l2(bflip, a) < 1e-13
 
 
+def test_reference_second_image_shape_1002x2007(pkg, oracle):
+    """The shape of the reference's other shipped image (00042.jpg, 1002 x 2007): non-power-of-two
+    strips and chunks on every kernel, odd row count, 2 and 3 phases."""
+    nx, ny = 1002, 2007
+    rng = np.random.default_rng(42)
+    f = np.kron(rng.random((ny // 9 + 1, nx // 6 + 1)), np.ones((9, 6)))[:ny, :nx]
+    pix = np.where(f < 0.5, 0, np.where(f < 0.72, 150, 255)).astype(np.uint8)
+    x0 = oracle.linear_guess(nx, ny, 0.0, 1.0)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-3)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    want = oracle.sweeps(A, b, x0, 21)
+    for kernel in KERNELS:
+        with pkg.Solver(nx, ny, kernel=kernel) as s:
+            s.set_image(pix)
+            s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            s.init_linear(0.0, 1.0)
+            s.sweeps(21)
+            assert_field(s.get_field(), want)
+    grid, _ = oracle.floodfill((pix > 200).astype(np.uint32))
+    D3 = oracle.fill_D_3phase(pix, 1.0, 0.0, 1237500.0)
+    with np.errstate(all="ignore"):
+        A3, b3 = oracle.discretize(D3, 0.0, 1.0, grid=grid)
+        want3 = oracle.sweeps(A3, b3, x0, 21)
+    with pkg.Solver(nx, ny) as s:
+        s.set_image(pix)
+        s.assemble_3phase(0.0, 1.0, 1237500.0, 0.0, 1.0, grid)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(21)
+        assert s.kernel_in_use() == "matfree_tb"
+        assert_field(s.get_field(), want3)
+
+
+@pytest.mark.parametrize("Ds,Df,CL,CR", [(1e-6, 1.0, 0.0, 1.0), (1.0, 1237500.0, 0.0, 1.0), (0.3, 2.0, 2.0, -1.0),
+                                         (5e-324, 1.0, 0.0, 1.0)])
+def test_extreme_contrasts_and_boundary_values(pkg, oracle, Ds, Df, CL, CR):
+    """Phase contrasts of 1e6 (the range the reference's documentation validates, doc 5.3), a gas-like
+    1 237 500, reversed / negative wall concentrations, a denormal diffusivity: same bits as the oracle."""
+    nx, ny = 100, 100
+    pix = np.full((ny, nx), 255, dtype=np.uint8)
+    pix[:, :37] = 0                              # series stripes
+    pix[40:60, 50:80] = 0
+    D = oracle.fill_D_2phase(pix, Df, Ds)
+    with np.errstate(all="ignore"):
+        A, b = oracle.discretize(D, CL, CR)
+        x0 = oracle.linear_guess(nx, ny, CL, CR)
+        it, deff, conv, x, _, _ = oracle.jacobi(A, b, x0, D, CL, CR, 1e-5, 3000, check_every=500)
+    for kernel in ("matfree_tb", "explicit"):
+        with pkg.Solver(nx, ny, kernel=kernel) as s:
+            s.set_image(pix)
+            s.assemble_2phase(Ds, Df, CL, CR)
+            s.init_linear(CL, CR)
+            r = s.solve(1e-5, 3000, check_every=500)
+            assert (r.iters, r.deff_raw, r.conv) == (it, deff, conv) or (np.isnan(deff) and np.isnan(r.deff_raw))
+            assert_field(s.get_field(), x)
+
+
 def test_errors_are_loud(pkg):
     with pkg.Solver(16, 16) as s:
         with pytest.raises(pkg.DeffError):
