@@ -25,7 +25,7 @@ SYMBOLS = [
     "deff_slab_group_set_image", "deff_slab_group_synth_image", "deff_slab_group_assemble_2phase",
     "deff_slab_group_init_linear", "deff_slab_group_set_field", "deff_slab_group_get_field",
     "deff_slab_group_sweeps", "deff_slab_group_flux", "deff_slab_group_solve",
-    "deff_rccl_unique_id", "deff_slab_rank_create", "deff_slab_rank_destroy", "deff_slab_rank_layout",
+    "deff_rccl_unique_id", "deff_slab_rank_create", "deff_slab_rank_create_custom", "deff_slab_rank_destroy", "deff_slab_rank_layout",
     "deff_slab_rank_window", "deff_slab_rank_context", "deff_slab_rank_set_image_window",
     "deff_slab_rank_synth_image", "deff_slab_rank_get_field", "deff_slab_rank_sweeps", "deff_slab_rank_solve",
     "deff_solve_stream", "deff_get_slot_field", "deff_debug_tb_stamps", "deff_flux", "deff_set_progress", "deff_last_launches", "deff_device_field", "deff_synchronize",
@@ -46,6 +46,9 @@ class Result(C.Structure):
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int64, C.c_double, C.c_double, C.c_void_p)
 NEXT_IMAGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int64))
 IMAGE_DONE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int, C.POINTER(Result))
+_cdp = C.POINTER(C.c_double)
+HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _cdp, _cdp, _cdp, _cdp, C.c_size_t)
+HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _cdp, _cdp, C.c_size_t)
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 _lib = None
@@ -119,6 +122,8 @@ def load():
                                         C.c_void_p, C.c_void_p]
     L.deff_rccl_unique_id.argtypes = [C.c_char_p]
     L.deff_slab_rank_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(ctx)]
+    L.deff_slab_rank_create_custom.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, HOST_EXCHANGE_FN,
+                                               HOST_ALLGATHER_FN, C.c_void_p, C.POINTER(ctx)]
     L.deff_slab_rank_destroy.argtypes = [ctx]
     L.deff_slab_rank_layout.argtypes = [ctx, ip, ip]
     L.deff_slab_rank_window.argtypes = [ctx, ip, ip]

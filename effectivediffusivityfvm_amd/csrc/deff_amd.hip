@@ -1802,6 +1802,12 @@ struct deff_slab_rank {
     std::vector<int> g0, own;
     double *d_pack = nullptr, *d_all = nullptr;      // [2*maxown], [nranks*2*maxown]
     std::vector<double> h_all, mfl, mfr;
+    // host-staged custom transport (deff_slab_rank_create_custom): the same loop, the blocks go
+    // through host buffers and the caller's callbacks instead of RCCL
+    deff_host_exchange_fn xchg = nullptr;
+    deff_host_allgather_fn gather = nullptr;
+    void *user = nullptr;
+    std::vector<double> h_send_up, h_send_dn, h_recv_up, h_recv_dn, h_pack;
 };
 
 #define NCCL_TRY(expr)                                                                          \
@@ -1833,10 +1839,34 @@ extern "C" int deff_slab_rank_destroy(deff_slab_rank *s)
     return DEFF_OK;
 }
 
+static int slab_rank_create_impl(int device, int nx, int NY, int rank, int nranks, const char *id128,
+                                 deff_host_exchange_fn xchg, deff_host_allgather_fn gather, void *user,
+                                 deff_slab_rank **out);
+
 extern "C" int deff_slab_rank_create(int device, int nx, int NY, int rank, int nranks, const char *id128,
                                      deff_slab_rank **out)
 {
-    if (!out || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(DEFF_EINVAL, "bad slab rank arguments");
+    if (!id128) return fail(DEFF_EINVAL, "RCCL id is NULL");
+    return slab_rank_create_impl(device, nx, NY, rank, nranks, id128, nullptr, nullptr, nullptr, out);
+}
+
+// Same slabs and loop with a caller-supplied transport: after every pass the two 8-row blocks are
+// copied to the host and handed to `exchange`, the fluxes to `allgather` (both collective over the
+// ranks).  Slow (host staged) but runs anywhere -- e.g. two processes sharing one GPU under gloo,
+// which is how the per-rank loop is tested across real process boundaries.
+extern "C" int deff_slab_rank_create_custom(int device, int nx, int NY, int rank, int nranks,
+                                            deff_host_exchange_fn exchange, deff_host_allgather_fn allgather,
+                                            void *user, deff_slab_rank **out)
+{
+    if (!exchange || !allgather) return fail(DEFF_EINVAL, "transport callbacks are NULL");
+    return slab_rank_create_impl(device, nx, NY, rank, nranks, nullptr, exchange, allgather, user, out);
+}
+
+static int slab_rank_create_impl(int device, int nx, int NY, int rank, int nranks, const char *id128,
+                                 deff_host_exchange_fn xchg, deff_host_allgather_fn gather, void *user,
+                                 deff_slab_rank **out)
+{
+    if (!out || nranks < 1 || rank < 0 || rank >= nranks) return fail(DEFF_EINVAL, "bad slab rank arguments");
     *out = nullptr;
     if (nx < 2 || (nx & 1)) return fail(DEFF_EINVAL, "row-slab mode needs an even nx >= 2 (got %d)", nx);
     if (NY / nranks < SLAB_HALO) return fail(DEFF_EINVAL, "%d rows over %d ranks: fewer than %d rows per slab", NY, nranks, SLAB_HALO);
@@ -1850,14 +1880,21 @@ extern "C" int deff_slab_rank_create(int device, int nx, int NY, int rank, int n
     }
     s->mfl.assign(NY, 0.0); s->mfr.assign(NY, 0.0);
     s->h_all.assign((size_t)nranks * 2 * s->maxown, 0.0);
+    s->xchg = xchg; s->gather = gather; s->user = user;
+    const size_t blk = (size_t)SLAB_HALO * nx;
+    if (xchg) {
+        s->h_send_up.assign(blk, 0.0); s->h_send_dn.assign(blk, 0.0);
+        s->h_recv_up.assign(blk, 0.0); s->h_recv_dn.assign(blk, 0.0);
+        s->h_pack.assign((size_t)2 * s->maxown, 0.0);
+    }
     int rc = slab_create_ctx(device, nx, NY, s->g0[rank], s->own[rank], &s->ctx);
     if (rc == DEFF_OK) {
         ncclUniqueId id;
-        memcpy(&id, id128, sizeof id);
+        if (id128) memcpy(&id, id128, sizeof id);
         hipError_t he;
         ncclResult_t nr;
         if ((he = hipSetDevice(device)) != hipSuccess) rc = fail(DEFF_EHIP, "hipSetDevice: %s", hipGetErrorString(he));
-        else if ((nr = ncclCommInitRank(&s->comm, nranks, id, rank)) != ncclSuccess)
+        else if (id128 && (nr = ncclCommInitRank(&s->comm, nranks, id, rank)) != ncclSuccess)
             rc = fail(DEFF_ECOMM, "ncclCommInitRank: %s", ncclGetErrorString(nr));
         else if ((he = hipMalloc((void **)&s->d_pack, sizeof(double) * 2 * s->maxown)) != hipSuccess ||
                  (he = hipMalloc((void **)&s->d_all, sizeof(double) * 2 * s->maxown * nranks)) != hipSuccess)
@@ -1950,6 +1987,21 @@ static int rank_exchange(deff_slab_rank *s)
     deff_ctx *c = s->ctx;
     const size_t blk = (size_t)SLAB_HALO * s->nx;
     double *x = c->x[c->cur];
+    if (s->xchg) {                                               // host-staged custom transport
+        const bool up = s->rank > 0, dn = s->rank + 1 < s->nranks;
+        double *top_own = x + (size_t)c->own_lo * s->nx, *bot_own = x + (size_t)(c->own_lo + c->own_h - SLAB_HALO) * s->nx;
+        if (up) HIP_TRY(hipMemcpyAsync(s->h_send_up.data(), top_own, sizeof(double) * blk, hipMemcpyDeviceToHost, c->stream));
+        if (dn) HIP_TRY(hipMemcpyAsync(s->h_send_dn.data(), bot_own, sizeof(double) * blk, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (s->xchg(s->user, up ? s->h_send_up.data() : nullptr, up ? s->h_recv_up.data() : nullptr,
+                    dn ? s->h_send_dn.data() : nullptr, dn ? s->h_recv_dn.data() : nullptr, blk) != 0)
+            return fail(DEFF_ECOMM, "custom halo exchange failed");
+        if (up) HIP_TRY(hipMemcpyAsync(x, s->h_recv_up.data(), sizeof(double) * blk, hipMemcpyHostToDevice, c->stream));
+        if (dn) HIP_TRY(hipMemcpyAsync(x + (size_t)(c->own_lo + c->own_h) * s->nx, s->h_recv_dn.data(), sizeof(double) * blk,
+                                       hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));                // the host buffers are reused by the next pass
+        return DEFF_OK;
+    }
     NCCL_TRY(ncclGroupStart());
     if (s->rank > 0) {
         NCCL_TRY(ncclSend(x + (size_t)c->own_lo * s->nx, blk, ncclDouble, s->rank - 1, s->comm, c->stream));
@@ -2023,9 +2075,16 @@ static int rank_flux(deff_slab_rank *s, double *deff_raw)
     hipLaunchKernelGGL(k_pack_own_flux, dim3((c->own_h + 255) / 256), dim3(256), 0, c->stream, c->mf, c->rows, c->own_lo,
                        c->own_h, s->maxown, s->d_pack);
     HIP_TRY(hipGetLastError());
-    NCCL_TRY(ncclAllGather(s->d_pack, s->d_all, (size_t)2 * s->maxown, ncclDouble, s->comm, c->stream));
-    HIP_TRY(hipMemcpyAsync(s->h_all.data(), s->d_all, sizeof(double) * s->h_all.size(), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (s->gather) {
+        HIP_TRY(hipMemcpyAsync(s->h_pack.data(), s->d_pack, sizeof(double) * 2 * s->maxown, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (s->gather(s->user, s->h_pack.data(), s->h_all.data(), (size_t)2 * s->maxown) != 0)
+            return fail(DEFF_ECOMM, "custom flux all-gather failed");
+    } else {
+        NCCL_TRY(ncclAllGather(s->d_pack, s->d_all, (size_t)2 * s->maxown, ncclDouble, s->comm, c->stream));
+        HIP_TRY(hipMemcpyAsync(s->h_all.data(), s->d_all, sizeof(double) * s->h_all.size(), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     for (int r = 0; r < s->nranks; ++r) {
         const double *blk = s->h_all.data() + (size_t)r * 2 * s->maxown;
         memcpy(&s->mfl[s->g0[r]], blk, sizeof(double) * s->own[r]);

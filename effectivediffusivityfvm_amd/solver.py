@@ -324,16 +324,78 @@ def rccl_unique_id():
     return buf.raw
 
 
+class TorchDistTransport:
+    """Host-staged slab transport over a torch.distributed group of CPU tensors (gloo): the halo
+    blocks and the flux vectors arrive as host buffers, neighbours swap them with isend/irecv.
+    For tests and for boxes without a working RCCL path between the ranks; RCCL is the fast one."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist, self._group = torch, dist, group
+        self.rank, self.nranks = dist.get_rank(group), dist.get_world_size(group)
+
+    def _peer(self, r):
+        return r if self._group is None else self._dist.get_global_rank(self._group, r)
+
+    def exchange(self, send_up, recv_up, send_down, recv_down):
+        t, d = self._torch, self._dist
+        ops, keep = [], []
+        for send, recv, peer in ((send_up, recv_up, self.rank - 1), (send_down, recv_down, self.rank + 1)):
+            if send is None:
+                continue
+            st, rt = t.from_numpy(send.copy()), t.from_numpy(recv)
+            keep += [st, rt]
+            ops += [d.P2POp(d.isend, st, self._peer(peer), self._group), d.P2POp(d.irecv, rt, self._peer(peer), self._group)]
+        for w in (d.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+
+    def allgather(self, mine, out):
+        t, d = self._torch, self._dist
+        parts = [t.from_numpy(out[r]) for r in range(self.nranks)]
+        d.all_gather(parts, t.from_numpy(mine.copy()), group=self._group)
+
+
 class SlabRank:
     """This process's slab of one image split over `nranks` processes (one GPU each); halo
-    exchange and flux all-gather go through RCCL.  solve() and sweeps() are collective."""
+    exchange and flux all-gather go through RCCL (`unique_id`), or through `transport` (an object
+    with exchange()/allgather() like TorchDistTransport) when unique_id is None.  solve() and
+    sweeps() are collective."""
 
-    def __init__(self, nx, NY, rank, nranks, unique_id, device=0):
+    def __init__(self, nx, NY, rank, nranks, unique_id=None, device=0, transport=None):
         self._L = _capi.load()
         self._s = C.c_void_p()
         self.nx, self.ny, self.rank, self.nranks = int(nx), int(NY), int(rank), int(nranks)
-        check(self._L.deff_slab_rank_create(int(device), self.nx, self.ny, self.rank, self.nranks, unique_id,
-                                            C.byref(self._s)))
+        if unique_id is not None:
+            check(self._L.deff_slab_rank_create(int(device), self.nx, self.ny, self.rank, self.nranks, unique_id,
+                                                C.byref(self._s)))
+        else:
+            if transport is None:
+                raise ValueError("SlabRank needs an RCCL unique_id or a transport")
+            self._transport, self._cb_error = transport, None
+
+            def as_np(p, n):
+                return np.ctypeslib.as_array(p, shape=(n,)) if p else None
+
+            def xchg(_user, su, ru, sd, rd, count):
+                try:
+                    transport.exchange(as_np(su, count), as_np(ru, count), as_np(sd, count), as_np(rd, count))
+                    return 0
+                except Exception as e:                         # noqa: BLE001 -- reported through the C error path
+                    self._cb_error = e
+                    return 1
+
+            def gather(_user, mine, out, count):
+                try:
+                    transport.allgather(as_np(mine, count), np.ctypeslib.as_array(out, shape=(self.nranks, count)))
+                    return 0
+                except Exception as e:                         # noqa: BLE001
+                    self._cb_error = e
+                    return 1
+
+            self._cbs = (_capi.HOST_EXCHANGE_FN(xchg), _capi.HOST_ALLGATHER_FN(gather))   # keep alive
+            check(self._L.deff_slab_rank_create_custom(int(device), self.nx, self.ny, self.rank, self.nranks,
+                                                       self._cbs[0], self._cbs[1], None, C.byref(self._s)))
         self._ctx = C.c_void_p()
         check(self._L.deff_slab_rank_context(self._s, C.byref(self._ctx)))
 

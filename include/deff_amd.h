@@ -183,6 +183,15 @@ typedef struct deff_slab_rank deff_slab_rank;
 int deff_rccl_unique_id(char *id128);
 int deff_slab_rank_create(int device, int nx, int NY, int rank, int nranks, const char *id128,
                           deff_slab_rank **out);
+/* the same slab with a caller-supplied, host-staged transport instead of RCCL (testing, portability):
+ *   exchange(user, send_up, recv_up, send_down, recv_down, count): swap `count` doubles with the
+ *     rank above (NULL pointers on the first rank) and below (NULL on the last); 0 = ok
+ *   allgather(user, mine, all, count): all[r*count ..] = rank r's `mine`; 0 = ok */
+typedef int (*deff_host_exchange_fn)(void *user, const double *send_up, double *recv_up, const double *send_down,
+                                     double *recv_down, size_t count);
+typedef int (*deff_host_allgather_fn)(void *user, const double *mine, double *all, size_t count);
+int deff_slab_rank_create_custom(int device, int nx, int NY, int rank, int nranks, deff_host_exchange_fn exchange,
+                                 deff_host_allgather_fn allgather, void *user, deff_slab_rank **out);
 int deff_slab_rank_destroy(deff_slab_rank *s);
 int deff_slab_rank_layout(const deff_slab_rank *s, int *first_row, int *row_count);   /* rows it owns */
 int deff_slab_rank_window(const deff_slab_rank *s, int *first_row, int *row_count);   /* rows it holds */
