@@ -96,7 +96,12 @@ __device__ __forceinline__ double tb_cell(const double *lut, unsigned off, doubl
 // group-of-three double buffer -- fewer VGPRs (94/118 at T=4/6) but 5-8 % slower, the batched
 // loads matter; T = 8 squeezed to 128 VGPRs for 4 waves/SIMD -- spills, 45 % slower;
 // 4 cells per lane -- 244 VGPRs, 2 waves/SIMD, 20 % slower;
-// a skewed pipeline whose T updates per step are independent -- 198 VGPRs, no faster.  The
+// a skewed pipeline whose T updates per step are independent -- 198 VGPRs, no faster;
+// one lookup per FACE instead of per cell (a symmetric dictionary has aE(i) = aW(i+1), aN(r) =
+// aS(r-1): take aE from the lane's other cell / the next lane by DPP and carry aS down one step;
+// 6 instead of 10 ds_read_b64 per lane and level) -- +4 % at T=4, +5 % at T=6, 0 at T=8 where the
+// carried values cost a wave of occupancy: the LDS (CDNA4: 2 clocks per ds_read_b64) is ~45 % busy,
+// the lookups' latency matters, not their number.  The
 // code is deliberately written with double2 values and named slots: an array-of-scalars
 // formulation of the same dataflow made hipcc hoist the lookups to 204 VGPRs.)
 template <int T, bool GUARD, bool WALL>
