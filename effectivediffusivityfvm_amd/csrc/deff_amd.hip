@@ -189,6 +189,23 @@ static inline int grid_for(size_t n, int cap = 16384)
 
 static CoefSoA soa_of(deff_ctx *c) { return CoefSoA{c->a0, c->aW, c->aE, c->aS, c->aN, c->b}; }
 
+// No C++ exception may unwind through the C ABI: every `extern "C" int` entry point is a
+// function-try-block ending in DEFF_API_CATCH, which turns std::bad_alloc (host vectors sized by the
+// caller's image) and anything else into an error code + message.
+static int api_exception() noexcept
+{
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        return fail(DEFF_ENOMEM, "host allocation failed");
+    } catch (const std::exception &e) {
+        return fail(DEFF_EINVAL, "internal error: %s", e.what());
+    } catch (...) {
+        return fail(DEFF_EINVAL, "internal error: unknown exception");
+    }
+}
+#define DEFF_API_CATCH catch (...) { return api_exception(); }
+
 // ---------------------------------------------------------- library -------
 
 extern "C" const char *deff_version(void) { return "deff_amd 0.1 (gfx950)"; }
@@ -208,7 +225,7 @@ extern "C" const char *deff_error_string(int code)
 }
 
 extern "C" int deff_device_count(int *count)
-{
+try {
     if (!count) return fail(DEFF_EINVAL, "count is NULL");
     int k = 0;
     hipError_t e = hipGetDeviceCount(&k);
@@ -216,16 +233,18 @@ extern "C" int deff_device_count(int *count)
     *count = k;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // -------------------------------------------------------- lifecycle -------
 
 extern "C" int deff_create(int device, int nx, int ny, deff_ctx **out)
-{
+try {
     return deff_create_batch(device, nx, ny, 1, out);
 }
+DEFF_API_CATCH
 
 extern "C" int deff_create_batch(int device, int nx, int ny, int nimg, deff_ctx **out)
-{
+try {
     if (!out) return fail(DEFF_EINVAL, "out is NULL");
     *out = nullptr;
     if (nx < 2 || ny < 2) return fail(DEFF_EINVAL, "mesh must be at least 2x2 (got %dx%d)", nx, ny);
@@ -269,9 +288,10 @@ extern "C" int deff_create_batch(int device, int nx, int ny, int nimg, deff_ctx 
     *out = c;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_destroy(deff_ctx *c)
-{
+try {
     if (!c) return DEFF_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -285,9 +305,10 @@ extern "C" int deff_destroy(deff_ctx *c)
     delete c;                      // no hipDeviceReset (the reference resets per image, cuh:1015)
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_mesh(const deff_ctx *c, int *nx, int *ny, double *dx, double *dy)
-{
+try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     if (nx) *nx = c->nx;
     if (ny) *ny = c->ny;
@@ -295,13 +316,15 @@ extern "C" int deff_mesh(const deff_ctx *c, int *nx, int *ny, double *dx, double
     if (dy) *dy = c->dy;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_batch_size(const deff_ctx *c, int *nimg)
-{
+try {
     if (!c || !nimg) return fail(DEFF_EINVAL, "NULL argument");
     *nimg = c->nimg;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // All images iterate again and their newest field is in x[cur] (after a new guess / system).
 static void reset_batch_state(deff_ctx *c)
@@ -312,13 +335,14 @@ static void reset_batch_state(deff_ctx *c)
 }
 
 extern "C" int deff_set_kernel(deff_ctx *c, int kernel)
-{
+try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     if (kernel < DEFF_KERNEL_AUTO || kernel > DEFF_KERNEL_MATFREE_TB)
         return fail(DEFF_EINVAL, "unknown kernel id %d", kernel);
     c->kernel = kernel;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // Which kernel a sweep will use, given what has been assembled.
 static int resolve_kernel(const deff_ctx *c, int *k)
@@ -344,13 +368,14 @@ static int resolve_kernel(const deff_ctx *c, int *k)
 }
 
 extern "C" int deff_get_kernel(const deff_ctx *c, int *k)
-{
+try {
     if (!c || !k) return fail(DEFF_EINVAL, "NULL argument");
     return resolve_kernel(c, k);
 }
+DEFF_API_CATCH
 
 extern "C" int deff_set_tuning(deff_ctx *c, const char *key, int value)
-{
+try {
     if (!c || !key) return fail(DEFF_EINVAL, "NULL argument");
     if (value < 0) return fail(DEFF_EINVAL, "tuning value must be >= 0");
     if (!strcmp(key, "rows_explicit")) c->rows_explicit = value;
@@ -367,6 +392,7 @@ extern "C" int deff_set_tuning(deff_ctx *c, const char *key, int value)
     else return fail(DEFF_EINVAL, "unknown tuning key '%s'", key);
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // ------------------------------------------------------------ image -------
 
@@ -384,7 +410,7 @@ static int image_shape(deff_ctx *c, int W, int H, int ampX, int ampY)
 }
 
 extern "C" int deff_set_image(deff_ctx *c, const uint8_t *pix, int W, int H, int ampX, int ampY)
-{
+try {
     if (!c || !pix) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
     TRY(image_shape(c, W, H, ampX, ampY));
@@ -394,9 +420,10 @@ extern "C" int deff_set_image(deff_ctx *c, const uint8_t *pix, int W, int H, int
     c->have_matfree = false;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_synth_image(deff_ctx *c, uint64_t seed, uint64_t img)
-{
+try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     TRY(use_device(c));
     TRY(image_shape(c, c->nx, c->ny, 1, 1));
@@ -408,9 +435,10 @@ extern "C" int deff_synth_image(deff_ctx *c, uint64_t seed, uint64_t img)
     c->have_matfree = false;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_get_image(deff_ctx *c, uint8_t *pix)
-{
+try {
     if (!c || !pix) return fail(DEFF_EINVAL, "NULL argument");
     if (!c->have_image) return fail(DEFF_ESTATE, "no image set");
     TRY(use_device(c));
@@ -418,6 +446,7 @@ extern "C" int deff_get_image(deff_ctx *c, uint8_t *pix)
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // --------------------------------------------------------- assembly -------
 
@@ -466,7 +495,7 @@ static int upload_lut(deff_ctx *c, double omega)
 }
 
 extern "C" int deff_assemble_2phase(deff_ctx *c, double Ds, double Df, double CL, double CR)
-{
+try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     if (!c->have_image) return fail(DEFF_ESTATE, "deff_assemble_2phase needs an image");
     TRY(use_device(c));
@@ -491,6 +520,7 @@ extern "C" int deff_assemble_2phase(deff_ctx *c, double Ds, double Df, double CL
     c->have_explicit = false;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // Explicit SoA planes for the native 2-phase system: D from the pixels
 // (cuh:1988-2000), then the general assembly.  Only needed when an explicit
@@ -519,7 +549,7 @@ static int explicit_from_image(deff_ctx *c)
 // coefficient planes: identity rows and zero-diffusivity links need the guarded general kernel.
 extern "C" int deff_assemble_3phase(deff_ctx *c, double Ds, double Df, double Dg, const unsigned int *Grid,
                                     double CL, double CR)
-{
+try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     if (!c->have_image) return fail(DEFF_ESTATE, "deff_assemble_3phase needs an image");
     TRY(use_device(c));
@@ -543,22 +573,24 @@ extern "C" int deff_assemble_3phase(deff_ctx *c, double Ds, double Df, double Dg
     c->have_matfree = false; c->dict_tried = false;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // FloodFill, cuh:557-713 (host, see flood_fill.hpp).  Grid: 1 = solid on entry; unreachable
 // non-solid cells are set to 2; *path_flag receives PathFlag.
 extern "C" int deff_flood_fill(unsigned int *Grid, int nx, int ny, int *path_flag)
-{
+try {
     if (!Grid || nx < 1 || ny < 1) return fail(DEFF_EINVAL, "bad flood-fill arguments");
     const int flag = flood_fill(Grid, nx, ny);
     if (path_flag) *path_flag = flag;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // Grayscale JPEG -> bytes, the reference's readImage (cuh:327-345: stbi_load(name,&w,&h,&n,1)).
 // *pix is malloc'ed (release with deff_free); *nChannels is the file's component count and is set
 // even when the call fails because the image is not single-channel (the reference's check).
 extern "C" int deff_load_jpeg_gray(const char *path, uint8_t **pix, int *W, int *H, int *nChannels)
-{
+try {
     if (!path || !pix || !W || !H) return fail(DEFF_EINVAL, "NULL argument");
     std::vector<uint8_t> buf;
     std::string err;
@@ -572,6 +604,7 @@ extern "C" int deff_load_jpeg_gray(const char *path, uint8_t **pix, int *W, int 
     memcpy(*pix, buf.data(), buf.size());
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" void deff_free(void *p) { free(p); }
 
@@ -580,7 +613,7 @@ static const size_t CHUNK_CELLS = (size_t)1 << 22;   // 4 Mi cells
 
 extern "C" int deff_assemble_from_D(deff_ctx *c, const double *D, const unsigned int *Grid, double CL,
                                     double CR)
-{
+try {
     if (!c || !D) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
     TRY(ensure_explicit(c));
@@ -602,10 +635,11 @@ extern "C" int deff_assemble_from_D(deff_ctx *c, const double *D, const unsigned
     c->have_matfree = false; c->dict_tried = false;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_set_system(deff_ctx *c, const double *A, const double *b, const double *D, double CL,
                                double CR)
-{
+try {
     if (!c || !A || !b) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
     TRY(ensure_explicit(c));
@@ -639,9 +673,10 @@ extern "C" int deff_set_system(deff_ctx *c, const double *A, const double *b, co
     c->have_matfree = false; c->dict_tried = false;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_get_system(deff_ctx *c, double *A, double *b)
-{
+try {
     if (!c || !A || !b) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
     if (c->have_explicit) {
@@ -673,11 +708,12 @@ extern "C" int deff_get_system(deff_ctx *c, double *A, double *b)
     }
     return fail(DEFF_ESTATE, "no system assembled");
 }
+DEFF_API_CATCH
 
 // ------------------------------------------------------------ field -------
 
 extern "C" int deff_init_linear(deff_ctx *c, double CL, double CR)
-{
+try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     TRY(use_device(c));
     hipLaunchKernelGGL(k_init_linear, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->x[c->cur], c->nx,
@@ -687,6 +723,7 @@ extern "C" int deff_init_linear(deff_ctx *c, double CL, double CR)
     reset_batch_state(c);
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // After a batch solve the images that converged earlier sit frozen in whichever ping-pong
 // buffer was current at that moment; bring every image's newest field into x[cur].
@@ -706,7 +743,7 @@ static int consolidate(deff_ctx *c)
 }
 
 extern "C" int deff_set_field(deff_ctx *c, const double *x)
-{
+try {
     if (!c || !x) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
     HIP_TRY(hipMemcpyAsync(c->x[c->cur], x, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
@@ -715,9 +752,10 @@ extern "C" int deff_set_field(deff_ctx *c, const double *x)
     reset_batch_state(c);
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_get_field(deff_ctx *c, double *x)
-{
+try {
     if (!c || !x) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
     TRY(consolidate(c));
@@ -725,9 +763,10 @@ extern "C" int deff_get_field(deff_ctx *c, double *x)
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_device_field(deff_ctx *c, void **d_x, size_t *pitch)
-{
+try {
     if (!c || !d_x) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
     TRY(consolidate(c));
@@ -735,14 +774,16 @@ extern "C" int deff_device_field(deff_ctx *c, void **d_x, size_t *pitch)
     if (pitch) *pitch = sizeof(double) * c->nx;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_synchronize(deff_ctx *c)
-{
+try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     TRY(use_device(c));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // ----------------------------------------------------------- sweeps -------
 
@@ -1051,7 +1092,7 @@ static inline void enqueue_sweeps(deff_ctx *c, const SweepPlan &pl, int64_t n)
 }
 
 extern "C" int deff_sweeps(deff_ctx *c, int64_t nsweeps, double omega, float *ms)
-{
+try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     if (nsweeps < 0) return fail(DEFF_EINVAL, "negative sweep count");
     TRY(use_device(c));
@@ -1067,6 +1108,7 @@ extern "C" int deff_sweeps(deff_ctx *c, int64_t nsweeps, double omega, float *ms
     if (ms) HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // Wall fluxes of the current field (cuh:1256-1257) for every stacked row, brought to the
 // pinned host buffer: mf_host[0..rows) left wall, mf_host[rows..2*rows) right wall.
@@ -1103,7 +1145,7 @@ static void copy_fluxes(const deff_ctx *c, double *MFL, double *MFR)
 
 // deff_raw: nimg values (one per stacked image); MFL/MFR: rows values each, may be NULL.
 extern "C" int deff_flux(deff_ctx *c, double *deff_raw, double *MFL, double *MFR)
-{
+try {
     if (!c || !deff_raw) return fail(DEFF_EINVAL, "NULL argument");
     if (!c->have_field) return fail(DEFF_ESTATE, "no field");
     TRY(use_device(c));
@@ -1113,6 +1155,7 @@ extern "C" int deff_flux(deff_ctx *c, double *deff_raw, double *MFL, double *MFR
     copy_fluxes(c, MFL, MFR);
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // JacobiGPU's loop, cuh:1232-1290, with the sweeps between two checks enqueued without host
 // round trips.  `iter` counts completed sweeps; the sweep with 0-based index k is followed by a
@@ -1122,7 +1165,7 @@ extern "C" int deff_flux(deff_ctx *c, double *deff_raw, double *MFL, double *MFR
 // of the reference's loop would do.
 extern "C" int deff_solve_batch(deff_ctx *c, double omega, double tol, int64_t max_iter, int64_t check_every,
                                 deff_result *out, double *MFL, double *MFR)
-{
+try {
     if (!c || !out) return fail(DEFF_EINVAL, "NULL argument");
     if (check_every < 1) return fail(DEFF_EINVAL, "check_every must be >= 1");
     TRY(use_device(c));
@@ -1193,6 +1236,7 @@ extern "C" int deff_solve_batch(deff_ctx *c, double omega, double tol, int64_t m
     }
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // ---- streaming batch ---------------------------------------------------------------------
 //
@@ -1237,7 +1281,7 @@ static int stream_push_mask(deff_ctx *c, int n_active)
 }
 
 extern "C" int deff_get_slot_field(deff_ctx *c, int slot, double *x)
-{
+try {
     if (!c || !x || slot < 0 || slot >= c->nimg) return fail(DEFF_EINVAL, "bad slot");
     TRY(use_device(c));
     HIP_TRY(hipMemcpyAsync(x, c->x[(c->masked || c->in_stream) ? c->buf_of[slot] : c->cur] + (size_t)slot * c->n_img,
@@ -1245,11 +1289,12 @@ extern "C" int deff_get_slot_field(deff_ctx *c, int slot, double *x)
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_solve_stream(deff_ctx *c, int W, int H, int ampX, int ampY, double Ds, double Df, double CL,
                                  double CR, double omega, double tol, int64_t max_iter, int64_t check_every,
                                  deff_next_image_fn next, deff_image_done_fn done, void *user)
-{
+try {
     if (!c || !next || !done) return fail(DEFF_EINVAL, "NULL argument");
     if (check_every < 1) return fail(DEFF_EINVAL, "check_every must be >= 1");
     if (c->slab) return fail(DEFF_EINVAL, "not for slab contexts");
@@ -1371,19 +1416,21 @@ extern "C" int deff_solve_stream(deff_ctx *c, int W, int H, int ampX, int ampY, 
     reset_batch_state(c);
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_solve(deff_ctx *c, double omega, double tol, int64_t max_iter, int64_t check_every,
                           deff_result *out, double *MFL, double *MFR)
-{
+try {
     if (c && c->nimg != 1) return fail(DEFF_EINVAL, "context holds %d images: use deff_solve_batch()", c->nimg);
     return deff_solve_batch(c, omega, tol, max_iter, check_every, out, MFL, MFR);
 }
+DEFF_API_CATCH
 
 // Diagnostics: time-stamp every wave tile of ONE temporally blocked pass (100 MHz wall clock ticks).
 // out[2*k], out[2*k+1] = start, end of wave tile k; *ntiles = number of tiles (call with out = NULL
 // to size the buffer).  Advances the field by one pass.
 extern "C" int deff_debug_tb_stamps(deff_ctx *c, double omega, unsigned long long *out, int *ntiles)
-{
+try {
     if (!c || !ntiles) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
     SweepPlan pl;
@@ -1402,17 +1449,19 @@ extern "C" int deff_debug_tb_stamps(deff_ctx *c, double omega, unsigned long lon
     if (e != hipSuccess) return fail(DEFF_EHIP, "stamp readback failed: %s", hipGetErrorString(e));
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_set_progress(deff_ctx *c, deff_progress_fn fn, void *user)
-{
+try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     c->progress = fn;
     c->progress_user = user;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_last_launches(const deff_ctx *c, int64_t *launches, int *sweeps_per_pass)
-{
+try {
     if (!c || !launches) return fail(DEFF_EINVAL, "NULL argument");
     *launches = c->last_launches;
     if (sweeps_per_pass) {
@@ -1425,6 +1474,7 @@ extern "C" int deff_last_launches(const deff_ctx *c, int64_t *launches, int *swe
     }
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // ====================================================================== row slabs ==
 //
@@ -1470,7 +1520,7 @@ static int slab_create_ctx(int device, int nx, int NY, int g0, int own, deff_ctx
 }
 
 extern "C" int deff_slab_group_create(int nslabs, const int *devices, int nx, int NY, deff_slab_group **out)
-{
+try {
     if (!out || nslabs < 1) return fail(DEFF_EINVAL, "bad slab group arguments");
     *out = nullptr;
     if (nx < 2 || (nx & 1)) return fail(DEFF_EINVAL, "row-slab mode needs an even nx >= 2 (got %d)", nx);
@@ -1506,9 +1556,10 @@ extern "C" int deff_slab_group_create(int nslabs, const int *devices, int nx, in
     *out = g;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_slab_group_destroy(deff_slab_group *g)
-{
+try {
     if (!g) return DEFF_OK;
     for (size_t r = 0; r < g->ctx.size(); ++r) {
         if (r < g->done.size() && g->done[r]) { (void)hipSetDevice(g->ctx[r]->device); (void)hipEventDestroy(g->done[r]); }
@@ -1517,9 +1568,10 @@ extern "C" int deff_slab_group_destroy(deff_slab_group *g)
     delete g;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_slab_group_layout(const deff_slab_group *g, int *first_row, int *row_count)
-{
+try {
     if (!g) return fail(DEFF_EINVAL, "group is NULL");
     for (int r = 0; r < g->n; ++r) {
         if (first_row) first_row[r] = g->g0[r];
@@ -1527,6 +1579,7 @@ extern "C" int deff_slab_group_layout(const deff_slab_group *g, int *first_row, 
     }
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // Array rows [lo, hi) of slab r as mesh rows, clipped to the mesh.
 static void slab_window(const deff_slab_group *g, int r, int *mesh_first, int *array_first, int *count)
@@ -1541,7 +1594,7 @@ static void slab_window(const deff_slab_group *g, int r, int *mesh_first, int *a
 
 // pix: the whole image, NY x nx bytes (mesh amplification is not supported in slab mode)
 extern "C" int deff_slab_group_set_image(deff_slab_group *g, const uint8_t *pix)
-{
+try {
     if (!g || !pix) return fail(DEFF_EINVAL, "NULL argument");
     for (int r = 0; r < g->n; ++r) {
         deff_ctx *c = g->ctx[r];
@@ -1557,9 +1610,10 @@ extern "C" int deff_slab_group_set_image(deff_slab_group *g, const uint8_t *pix)
     }
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_slab_group_synth_image(deff_slab_group *g, uint64_t seed, uint64_t img)
-{
+try {
     if (!g) return fail(DEFF_EINVAL, "group is NULL");
     for (int r = 0; r < g->n; ++r) {
         deff_ctx *c = g->ctx[r];
@@ -1577,23 +1631,26 @@ extern "C" int deff_slab_group_synth_image(deff_slab_group *g, uint64_t seed, ui
     }
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_slab_group_assemble_2phase(deff_slab_group *g, double Ds, double Df, double CL, double CR)
-{
+try {
     if (!g) return fail(DEFF_EINVAL, "group is NULL");
     for (int r = 0; r < g->n; ++r) TRY(deff_assemble_2phase(g->ctx[r], Ds, Df, CL, CR));
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_slab_group_init_linear(deff_slab_group *g, double CL, double CR)
-{
+try {
     if (!g) return fail(DEFF_EINVAL, "group is NULL");
     for (int r = 0; r < g->n; ++r) TRY(deff_init_linear(g->ctx[r], CL, CR));     // a function of the column only
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_slab_group_set_field(deff_slab_group *g, const double *x)
-{
+try {
     if (!g || !x) return fail(DEFF_EINVAL, "NULL argument");
     for (int r = 0; r < g->n; ++r) {
         deff_ctx *c = g->ctx[r];
@@ -1609,9 +1666,10 @@ extern "C" int deff_slab_group_set_field(deff_slab_group *g, const double *x)
     }
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_slab_group_get_field(deff_slab_group *g, double *x)
-{
+try {
     if (!g || !x) return fail(DEFF_EINVAL, "NULL argument");
     for (int r = 0; r < g->n; ++r) {
         deff_ctx *c = g->ctx[r];
@@ -1622,6 +1680,7 @@ extern "C" int deff_slab_group_get_field(deff_slab_group *g, double *x)
     for (int r = 0; r < g->n; ++r) { TRY(use_device(g->ctx[r])); HIP_TRY(hipStreamSynchronize(g->ctx[r]->stream)); }
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // After a pass: every slab's halo rows of the NEW field are stale; refill them from the
 // neighbours' own rows.  Copies run on the receiver's stream once the sender's pass is done.
@@ -1698,7 +1757,7 @@ static int slab_plans(deff_slab_group *g, double omega, std::vector<SweepPlan> &
 }
 
 extern "C" int deff_slab_group_sweeps(deff_slab_group *g, int64_t n, double omega, float *ms)
-{
+try {
     if (!g || n < 0) return fail(DEFF_EINVAL, "bad arguments");
     std::vector<SweepPlan> plT, pl1;
     TRY(slab_plans(g, omega, plT, pl1));
@@ -1713,6 +1772,7 @@ extern "C" int deff_slab_group_sweeps(deff_slab_group *g, int64_t n, double omeg
     if (ms) HIP_TRY(hipEventElapsedTime(ms, c0->ev0, c0->ev1));
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // Wall fluxes of every slab's own rows -> the group's global arrays -> Deff (cuh:1252-1263),
 // summed in global row order exactly like the one-GPU path.
@@ -1733,18 +1793,19 @@ static int slab_flux(deff_slab_group *g, double *deff_raw)
 }
 
 extern "C" int deff_slab_group_flux(deff_slab_group *g, double *deff_raw, double *MFL, double *MFR)
-{
+try {
     if (!g || !deff_raw) return fail(DEFF_EINVAL, "NULL argument");
     TRY(slab_flux(g, deff_raw));
     if (MFL) memcpy(MFL, g->mfl.data(), sizeof(double) * g->NY);
     if (MFR) memcpy(MFR, g->mfr.data(), sizeof(double) * g->NY);
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // JacobiGPU's loop (cuh:1232-1290) over the slabs; same stopping rule as deff_solve.
 extern "C" int deff_slab_group_solve(deff_slab_group *g, double omega, double tol, int64_t max_iter,
                                      int64_t check_every, deff_result *out, double *MFL, double *MFR)
-{
+try {
     if (!g || !out) return fail(DEFF_EINVAL, "NULL argument");
     if (check_every < 1) return fail(DEFF_EINVAL, "check_every must be >= 1");
     std::vector<SweepPlan> plT, pl1;
@@ -1779,13 +1840,15 @@ extern "C" int deff_slab_group_solve(deff_slab_group *g, double omega, double to
     if (MFR) memcpy(MFR, g->mfr.data(), sizeof(double) * g->NY);
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_slab_group_set_tuning(deff_slab_group *g, const char *key, int value)
-{
+try {
     if (!g) return fail(DEFF_EINVAL, "group is NULL");
     for (int r = 0; r < g->n; ++r) TRY(deff_set_tuning(g->ctx[r], key, value));
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // ------------------------------------------------- row slabs, one process per GPU (RCCL) --
 //
@@ -1818,7 +1881,7 @@ struct deff_slab_rank {
     } while (0)
 
 extern "C" int deff_rccl_unique_id(char *id128)
-{
+try {
     if (!id128) return fail(DEFF_EINVAL, "id buffer is NULL");
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
     ncclUniqueId id;
@@ -1826,9 +1889,10 @@ extern "C" int deff_rccl_unique_id(char *id128)
     memcpy(id128, &id, sizeof id);
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_slab_rank_destroy(deff_slab_rank *s)
-{
+try {
     if (!s) return DEFF_OK;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
     if (s->d_pack) (void)hipFree(s->d_pack);
@@ -1838,6 +1902,7 @@ extern "C" int deff_slab_rank_destroy(deff_slab_rank *s)
     delete s;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 static int slab_rank_create_impl(int device, int nx, int NY, int rank, int nranks, const char *id128,
                                  deff_host_exchange_fn xchg, deff_host_allgather_fn gather, void *user,
@@ -1845,10 +1910,11 @@ static int slab_rank_create_impl(int device, int nx, int NY, int rank, int nrank
 
 extern "C" int deff_slab_rank_create(int device, int nx, int NY, int rank, int nranks, const char *id128,
                                      deff_slab_rank **out)
-{
+try {
     if (!id128) return fail(DEFF_EINVAL, "RCCL id is NULL");
     return slab_rank_create_impl(device, nx, NY, rank, nranks, id128, nullptr, nullptr, nullptr, out);
 }
+DEFF_API_CATCH
 
 // Same slabs and loop with a caller-supplied transport: after every pass the two 8-row blocks are
 // copied to the host and handed to `exchange`, the fluxes to `allgather` (both collective over the
@@ -1857,10 +1923,11 @@ extern "C" int deff_slab_rank_create(int device, int nx, int NY, int rank, int n
 extern "C" int deff_slab_rank_create_custom(int device, int nx, int NY, int rank, int nranks,
                                             deff_host_exchange_fn exchange, deff_host_allgather_fn allgather,
                                             void *user, deff_slab_rank **out)
-{
+try {
     if (!exchange || !allgather) return fail(DEFF_EINVAL, "transport callbacks are NULL");
     return slab_rank_create_impl(device, nx, NY, rank, nranks, nullptr, exchange, allgather, user, out);
 }
+DEFF_API_CATCH
 
 static int slab_rank_create_impl(int device, int nx, int NY, int rank, int nranks, const char *id128,
                                  deff_host_exchange_fn xchg, deff_host_allgather_fn gather, void *user,
@@ -1908,25 +1975,27 @@ static int slab_rank_create_impl(int device, int nx, int NY, int rank, int nrank
 }
 
 extern "C" int deff_slab_rank_layout(const deff_slab_rank *s, int *first_row, int *row_count)
-{
+try {
     if (!s) return fail(DEFF_EINVAL, "slab is NULL");
     if (first_row) *first_row = s->g0[s->rank];
     if (row_count) *row_count = s->own[s->rank];
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // the context behind the slab, for deff_set_tuning / deff_assemble_2phase / deff_init_linear
 extern "C" int deff_slab_rank_context(deff_slab_rank *s, deff_ctx **ctx)
-{
+try {
     if (!s || !ctx) return fail(DEFF_EINVAL, "NULL argument");
     *ctx = s->ctx;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // window = the rows of the whole image this rank's arrays cover (own rows + halo, clipped to the
 // mesh): *first_row, *row_count; the image upload below takes exactly those rows.
 extern "C" int deff_slab_rank_window(const deff_slab_rank *s, int *first_row, int *row_count)
-{
+try {
     if (!s) return fail(DEFF_EINVAL, "slab is NULL");
     const deff_ctx *c = s->ctx;
     int a = -c->dom_lo, b = a + c->rows;
@@ -1936,9 +2005,10 @@ extern "C" int deff_slab_rank_window(const deff_slab_rank *s, int *first_row, in
     if (row_count) *row_count = b - a;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_slab_rank_set_image_window(deff_slab_rank *s, const uint8_t *pix_window)
-{
+try {
     if (!s || !pix_window) return fail(DEFF_EINVAL, "NULL argument");
     deff_ctx *c = s->ctx;
     TRY(use_device(c));
@@ -1952,9 +2022,10 @@ extern "C" int deff_slab_rank_set_image_window(deff_slab_rank *s, const uint8_t 
     c->have_image = true; c->have_matfree = false;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 extern "C" int deff_slab_rank_synth_image(deff_slab_rank *s, uint64_t seed, uint64_t img)
-{
+try {
     if (!s) return fail(DEFF_EINVAL, "slab is NULL");
     deff_ctx *c = s->ctx;
     TRY(use_device(c));
@@ -1969,10 +2040,11 @@ extern "C" int deff_slab_rank_synth_image(deff_slab_rank *s, uint64_t seed, uint
     c->have_image = true; c->have_matfree = false;
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 // own rows of the current field -> host
 extern "C" int deff_slab_rank_get_field(deff_slab_rank *s, double *x_own)
-{
+try {
     if (!s || !x_own) return fail(DEFF_EINVAL, "NULL argument");
     deff_ctx *c = s->ctx;
     TRY(use_device(c));
@@ -1981,6 +2053,7 @@ extern "C" int deff_slab_rank_get_field(deff_slab_rank *s, double *x_own)
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 static int rank_exchange(deff_slab_rank *s)
 {
@@ -2044,7 +2117,7 @@ static int rank_plans(deff_slab_rank *s, double omega, SweepPlan *plT, SweepPlan
 }
 
 extern "C" int deff_slab_rank_sweeps(deff_slab_rank *s, int64_t n, double omega, float *ms)
-{
+try {
     if (!s || n < 0) return fail(DEFF_EINVAL, "bad arguments");
     SweepPlan plT, pl1;
     TRY(rank_plans(s, omega, &plT, &pl1));
@@ -2056,6 +2129,7 @@ extern "C" int deff_slab_rank_sweeps(deff_slab_rank *s, int64_t n, double omega,
     if (ms) HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
     return DEFF_OK;
 }
+DEFF_API_CATCH
 
 __global__ void k_pack_own_flux(const double *__restrict__ mf, int rows, int own_lo, int own_h, int maxown,
                                 double *__restrict__ pack)
@@ -2101,7 +2175,7 @@ static int rank_flux(deff_slab_rank *s, double *deff_raw)
 // and gets the same result (iters, Deff, conv); MFL/MFR receive the GLOBAL fluxes (NY each).
 extern "C" int deff_slab_rank_solve(deff_slab_rank *s, double omega, double tol, int64_t max_iter, int64_t check_every,
                                     deff_result *out, double *MFL, double *MFR)
-{
+try {
     if (!s || !out) return fail(DEFF_EINVAL, "NULL argument");
     if (check_every < 1) return fail(DEFF_EINVAL, "check_every must be >= 1");
     SweepPlan plT, pl1;
@@ -2133,3 +2207,4 @@ extern "C" int deff_slab_rank_solve(deff_slab_rank *s, double omega, double tol,
     if (MFR) memcpy(MFR, s->mfr.data(), sizeof(double) * s->NY);
     return DEFF_OK;
 }
+DEFF_API_CATCH

@@ -26,6 +26,21 @@ struct Options {                   // same meaning as the reference's `options`,
     int printCmap = 0, verbose = 0, BatchFlag = 0, NumImg = 1;
 };
 
+// double -> integer as the reference's casts do for sane values; NaN and out-of-range values
+// (undefined behaviour in a plain cast) are pinned to 0 / the range ends and fail validation later
+inline long to_long(double v)
+{
+    if (!(v == v)) return 0;
+    if (v >= 9.0e18) return (long)9000000000000000000L;
+    if (v <= -9.0e18) return (long)-9000000000000000000L;
+    return (long)v;
+}
+inline int to_int(double v)
+{
+    const long l = to_long(v);
+    return l > 2147483647L ? 2147483647 : (l < -2147483647L ? -2147483647 : (int)l);
+}
+
 inline bool read_input_file(const char *path, Options *o, std::string *err)
 {
     std::ifstream in(path);
@@ -41,20 +56,20 @@ inline bool read_input_file(const char *path, Options *o, std::string *err)
         if (k == "Ds:") o->DCsolid = v;
         else if (k == "Df:") o->DCfluid = v;
         else if (k == "Dg:") o->DCgas = v;
-        else if (k == "MeshAmpX:") o->MeshIncreaseX = (int)v;
-        else if (k == "MeshAmpY:") o->MeshIncreaseY = (int)v;
+        else if (k == "MeshAmpX:") o->MeshIncreaseX = to_int(v);
+        else if (k == "MeshAmpY:") o->MeshIncreaseY = to_int(v);
         else if (k == "InputName:") o->inputFilename = text;
         else if (k == "CR:") o->CRight = v;
         else if (k == "CL:") o->CLeft = v;
         else if (k == "OutputName:") o->outputFilename = text;
-        else if (k == "printCMap:") o->printCmap = (int)v;
+        else if (k == "printCMap:") o->printCmap = to_int(v);
         else if (k == "CMapName:") o->CMapName = text;
         else if (k == "Convergence:") o->ConvergeCriteria = v;
-        else if (k == "MaxIter:") o->MAX_ITER = (long)v;
-        else if (k == "Verbose:") o->verbose = (int)v;
-        else if (k == "RunBatch:") o->BatchFlag = (int)v;
-        else if (k == "NumImages:") o->NumImg = (int)v;
-        else if (k == "Phases:") o->nPhase = (int)v;
+        else if (k == "MaxIter:") o->MAX_ITER = to_long(v);
+        else if (k == "Verbose:") o->verbose = to_int(v);
+        else if (k == "RunBatch:") o->BatchFlag = to_int(v);
+        else if (k == "NumImages:") o->NumImg = to_int(v);
+        else if (k == "Phases:") o->nPhase = to_int(v);
     }
     if (o->nPhase != 2 && o->nPhase != 3) { *err = "Phases must be 2 or 3"; return false; }
     if (o->MeshIncreaseX < 1 || o->MeshIncreaseY < 1) {          // cuh:1901-1904
@@ -63,6 +78,8 @@ inline bool read_input_file(const char *path, Options *o, std::string *err)
     }
     if (o->verbose != 0 && o->verbose != 1)
         std::printf("Please enter a value of 0 or 1 for 'verbose'. Default = 0.\n");   // cuh:320-322
+    if (o->MAX_ITER < 1) { *err = "MaxIter must be >= 1"; return false; }
+    if (!(o->ConvergeCriteria == o->ConvergeCriteria)) { *err = "Convergence is not a number"; return false; }
     if (o->BatchFlag && o->NumImg < 1) { *err = "NumImages must be >= 1 in batch mode"; return false; }
     return true;
 }

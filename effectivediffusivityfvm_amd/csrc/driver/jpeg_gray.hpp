@@ -109,23 +109,26 @@ static const uint8_t ZIGZAG[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 2
 
 // 12-bit fixed-point constants of the LL&M factorisation
 constexpr int fx(double v) { return (int)(v * 4096 + 0.5); }
-struct Idct1D { int e0, e1, e2, e3, o0, o1, o2, o3; };             // even part x0..x3, odd part t0..t3
+// (64-bit intermediates: the values of a valid file fit 32 bits with room to spare, so the
+// results are those of 32-bit arithmetic; a damaged file can no longer overflow anything)
+typedef int64_t idct_t;
+struct Idct1D { idct_t e0, e1, e2, e3, o0, o1, o2, o3; };          // even part x0..x3, odd part t0..t3
 
-inline Idct1D idct_1d(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7)
+inline Idct1D idct_1d(idct_t s0, idct_t s1, idct_t s2, idct_t s3, idct_t s4, idct_t s5, idct_t s6, idct_t s7)
 {
     Idct1D r;
     // even part: rotation of (s2, s6), butterflies with (s0 +- s4) << 12
-    int z = (s2 + s6) * fx(0.5411961f);
-    int ev2 = z + s6 * fx(-1.847759065f);
-    int ev3 = z + s2 * fx(0.765366865f);
-    int ev0 = (s0 + s4) * 4096;
-    int ev1 = (s0 - s4) * 4096;
+    idct_t z = (s2 + s6) * fx(0.5411961f);
+    idct_t ev2 = z + s6 * fx(-1.847759065f);
+    idct_t ev3 = z + s2 * fx(0.765366865f);
+    idct_t ev0 = (s0 + s4) * 4096;
+    idct_t ev1 = (s0 - s4) * 4096;
     r.e0 = ev0 + ev3; r.e3 = ev0 - ev3;
     r.e1 = ev1 + ev2; r.e2 = ev1 - ev2;
     // odd part
-    int a = s7, b = s5, c = s3, d = s1;
-    int ac = a + c, bd = b + d, ad = a + d, bc = b + c;
-    int z5 = (ac + bd) * fx(1.175875602f);
+    idct_t a = s7, b = s5, c = s3, d = s1;
+    idct_t ac = a + c, bd = b + d, ad = a + d, bc = b + c;
+    idct_t z5 = (ac + bd) * fx(1.175875602f);
     a = a * fx(0.298631336f);
     b = b * fx(2.053119869f);
     c = c * fx(3.072711026f);
@@ -141,23 +144,23 @@ inline Idct1D idct_1d(int s0, int s1, int s2, int s3, int s4, int s5, int s6, in
     return r;
 }
 
-inline uint8_t clamp255(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+inline uint8_t clamp255(idct_t v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
 inline void idct_block(const int16_t c[64], uint8_t *out, int stride)
 {
-    int tmp[64];
+    idct_t tmp[64];
     for (int i = 0; i < 8; ++i) {                                  // columns, keep 2 extra bits
         Idct1D r = idct_1d(c[i], c[8 + i], c[16 + i], c[24 + i], c[32 + i], c[40 + i], c[48 + i], c[56 + i]);
-        const int rnd = 512;
+        const idct_t rnd = 512;
         tmp[i] = (r.e0 + rnd + r.o3) >> 10;       tmp[56 + i] = (r.e0 + rnd - r.o3) >> 10;
         tmp[8 + i] = (r.e1 + rnd + r.o2) >> 10;   tmp[48 + i] = (r.e1 + rnd - r.o2) >> 10;
         tmp[16 + i] = (r.e2 + rnd + r.o1) >> 10;  tmp[40 + i] = (r.e2 + rnd - r.o1) >> 10;
         tmp[24 + i] = (r.e3 + rnd + r.o0) >> 10;  tmp[32 + i] = (r.e3 + rnd - r.o0) >> 10;
     }
     for (int i = 0; i < 8; ++i) {                                  // rows: 12 + 2 + 3 bits to remove
-        const int *v = tmp + 8 * i;
+        const idct_t *v = tmp + 8 * i;
         Idct1D r = idct_1d(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-        const int rnd = 65536 + (128 << 17);                       // rounding + level shift
+        const idct_t rnd = 65536 + (128 << 17);                       // rounding + level shift
         uint8_t *o = out + (size_t)i * stride;
         o[0] = clamp255((r.e0 + rnd + r.o3) >> 17);  o[7] = clamp255((r.e0 + rnd - r.o3) >> 17);
         o[1] = clamp255((r.e1 + rnd + r.o2) >> 17);  o[6] = clamp255((r.e1 + rnd - r.o2) >> 17);
@@ -235,9 +238,13 @@ inline bool decode_gray(const uint8_t *data, size_t len, std::vector<uint8_t> &p
             const int td = seg[2] >> 4, ta = seg[2] & 15;
             if (td > 3 || ta > 3 || !dc[td].present || !ac[ta].present || !have_q[qid]) { err = "scan refers to a missing table"; return false; }
             const int bw = (w + 7) / 8, bh = (h + 7) / 8;
+            // a block takes at least 2 bits (shortest DC code + shortest end-of-block code): a header
+            // that promises more blocks than the file can hold is damaged -- refuse before allocating
+            if ((uint64_t)bw * bh > ((uint64_t)(len - (i + L)) * 8) / 2 + 1) { err = "scan data too short for the image size"; return false; }
             std::vector<uint8_t> padded((size_t)bw * 8 * bh * 8);
             BitReader br(data + i + L, data + len);
-            int pred = 0, todo = restart;
+            int64_t pred = 0;
+            int todo = restart;
             for (int by = 0; by < bh; ++by)
                 for (int bx = 0; bx < bw; ++bx) {
                     int16_t coef[64];
@@ -245,7 +252,7 @@ inline bool decode_gray(const uint8_t *data, size_t len, std::vector<uint8_t> &p
                     int t = decode_symbol(br, dc[td]);
                     if (t < 0 || t > 15) { err = "corrupt DC code"; return false; }
                     pred += t ? extend(br.bits(t), t) : 0;
-                    coef[0] = (int16_t)(pred * quant[qid][0]);
+                    coef[0] = (int16_t)(pred * quant[qid][0]);                 // int16 storage, as in stb_image
                     for (int k = 1; k < 64;) {
                         int rs = decode_symbol(br, ac[ta]);
                         if (rs < 0) { err = "corrupt AC code"; return false; }
@@ -257,7 +264,7 @@ inline bool decode_gray(const uint8_t *data, size_t len, std::vector<uint8_t> &p
                             k += r;
                             if (k > 63) { err = "corrupt block"; return false; }
                             const int z = ZIGZAG[k++];
-                            coef[z] = (int16_t)(extend(br.bits(s), s) * quant[qid][z]);
+                            coef[z] = (int16_t)((int64_t)extend(br.bits(s), s) * quant[qid][z]);
                         }
                     }
                     idct_block(coef, padded.data() + ((size_t)by * 8 * bw + bx) * 8, bw * 8);

@@ -109,6 +109,21 @@ def test_driver_input_errors_without_gpu(built, tmp_path):
     assert r.returncode == 1 and "MeshIncrease" in r.stderr
 
 
+def test_front_end_survives_damaged_input_under_sanitizers(tmp_path):
+    """JPEG decoder and input-file parser on 4 000 truncated / bit-flipped / spliced / random inputs,
+    built with AddressSanitizer + UBSan (CPU build): nothing may read out of bounds, overflow or
+    leak, and every rejection carries a message."""
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    exe = str(tmp_path / "frontend_fuzz")
+    subprocess.run(["make", "-s", "-C", cpp, "frontend_fuzz"], check=True)
+    shutil.copy(os.path.join(cpp, "frontend_fuzz"), exe)
+    img = str(tmp_path / "good.jpg")
+    shutil.copy(os.path.join(GOLDEN, "00000.jpg"), img)
+    r = subprocess.run([exe, img, "4000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "accepted" in r.stdout and "rejected" in r.stdout
+
+
 @pytest.mark.gpu
 def test_driver_2phase_batch_config1(built, tmp_path, recorded):
     """Config #1 through the command line: the reference's input.txt keys, 00000.jpg, RunBatch 1."""
