@@ -18,7 +18,7 @@ KERNEL_NAMES = {"auto": 0, "explicit": 1, "scalar": 2, "matfree": 3, "matfree_tb
 SYMBOLS = [
     "deff_version", "deff_last_error", "deff_error_string", "deff_device_count",
     "deff_create", "deff_create_batch", "deff_batch_size", "deff_destroy", "deff_mesh", "deff_set_kernel", "deff_get_kernel",
-    "deff_set_tuning", "deff_set_image", "deff_synth_image", "deff_get_image",
+    "deff_set_tuning", "deff_get_plan", "deff_set_image", "deff_synth_image", "deff_get_image",
     "deff_load_jpeg_gray", "deff_free", "deff_assemble_2phase", "deff_assemble_3phase", "deff_flood_fill", "deff_assemble_from_D", "deff_set_system", "deff_get_system",
     "deff_init_linear", "deff_set_field", "deff_get_field", "deff_solve", "deff_solve_batch", "deff_sweeps",
     "deff_slab_group_create", "deff_slab_group_destroy", "deff_slab_group_layout", "deff_slab_group_set_tuning",
@@ -79,6 +79,7 @@ def load():
     L.deff_set_kernel.argtypes = [ctx, C.c_int]
     L.deff_get_kernel.argtypes = [ctx, C.POINTER(C.c_int)]
     L.deff_set_tuning.argtypes = [ctx, C.c_char_p, C.c_int]
+    L.deff_get_plan.argtypes = [ctx, C.c_char_p, C.POINTER(C.c_int)]
     L.deff_set_image.argtypes = [ctx, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.deff_synth_image.argtypes = [ctx, C.c_uint64, C.c_uint64]
     L.deff_get_image.argtypes = [ctx, _u8p]

@@ -136,6 +136,7 @@ struct deff_ctx {
     int tb_T = 0, tb_LY = 0, tb_wg = 0;          // temporal blocking: sweeps per pass, rows per chunk, workgroups
     unsigned long long *tb_stamps = nullptr;     // diagnostics: per wave-tile start/end clocks (deff_debug_tb_stamps)
     int tb_wall_halo = 2;                        // strip placement: 1 = halo also outside the walls, 0 = not, 2 = whichever needs fewer strips
+    int plan_T = 0, plan_LY = 0, plan_ntx = 0, plan_cpi = 0, plan_blocks = 0;   // last temporally blocked plan
     int tb_xmajor = 1;                           // wave-tile numbering of the temporally blocked kernel
     int64_t last_launches = 0;                   // sweep-kernel launches of the last deff_sweeps()/deff_solve()
 };
@@ -390,6 +391,20 @@ try {
     else if (!strcmp(key, "tb_wall_halo")) c->tb_wall_halo = value > 2 ? 2 : value;
     else if (!strcmp(key, "tb_wg")) c->tb_wg = (value + 7) / 8 * 8;
     else return fail(DEFF_EINVAL, "unknown tuning key '%s'", key);
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+// What the last plan of the temporally blocked kernel chose (0 before any sweep ran on it).
+extern "C" int deff_get_plan(deff_ctx *c, const char *key, int *value)
+try {
+    if (!c || !key || !value) return fail(DEFF_EINVAL, "NULL argument");
+    if (!strcmp(key, "tb_T")) *value = c->plan_T;
+    else if (!strcmp(key, "tb_LY")) *value = c->plan_LY;
+    else if (!strcmp(key, "tb_strips")) *value = c->plan_ntx;
+    else if (!strcmp(key, "tb_chunks_per_image")) *value = c->plan_cpi;
+    else if (!strcmp(key, "tb_blocks")) *value = c->plan_blocks;
+    else return fail(DEFF_EINVAL, "unknown plan key '%s'", key);
     return DEFF_OK;
 }
 DEFF_API_CATCH
@@ -953,22 +968,26 @@ static int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             const bool use_b = c->tb_wall_halo == 0 ? true : (c->tb_wall_halo == 1 ? false : ntx_b < ntx_a);
             pl->shift = use_b ? 0 : hw;
             pl->ntx = use_b ? ntx_b : ntx_a;
-            // Rows per chunk.  Workgroups are persistent and tiles cost the same, so the
-            // pass takes rounds x (LY + 2T) row steps, where one round is as many block
-            // tiles as are resident at once.  Pick the (rounds, LY) pair minimising that.
+            // Rows per chunk.  Workgroups are persistent, so a pass takes `rounds` tiles per wave slot
+            // (one round = as many wave tiles as are resident at once), and a tile costs its LY rows
+            // + T steps that drain the pipeline + T rows of halo above it unless it starts at the top
+            // wall of its image + a fixed start-up (first loads, measured ~8 row steps).  Pick the
+            // chunks per image minimising rounds x tile cost; for k rounds only the largest chunk
+            // count that fits matters.  (Stacks of small images: 3 072 x 128^2 as whole-image tiles
+            // 1 266 G cells*iter/s against 1 107 G for the 4 x 32-row tiles a halo-blind model picks.)
             int resident = c->tb_wg;
             if (!resident) TRY(tb_resident_blocks(c, T, pl->CPL, c->lut_guard, &resident));
             int LY = c->tb_LY;
             if (!LY) {
                 long best_cost = -1;
+                const bool top_wall = c->own_lo == 0;              // not a slab with rows above it
                 for (int k = 1; k <= 8; ++k) {
-                    // chunks per image such that nimg x ntx x chunks wave tiles fill k rounds of
-                    // `resident` workgroups (4 waves each)
-                    const int tgy_max = (int)(((long)k * resident * 4) / ((long)pl->ntx * c->nimg));
-                    if (tgy_max < 1) continue;
-                    int ly = (c->own_h + tgy_max - 1) / tgy_max;
+                    const int cpi_max = (int)(((long)k * resident * 4) / ((long)pl->ntx * c->nimg));
+                    if (cpi_max < 1) continue;
+                    int ly = (c->own_h + cpi_max - 1) / cpi_max;
                     if (ly < 1) ly = 1;
-                    const long cost = (long)k * (ly + 2 * T);
+                    const int cpi = (c->own_h + ly - 1) / ly;
+                    const long cost = (long)k * (ly + T + ((cpi > 1 || !top_wall) ? T : 0) + 8);
                     if (best_cost < 0 || cost < best_cost) { best_cost = cost; LY = ly; }
                 }
                 if (!LY) LY = c->own_h;
@@ -981,6 +1000,8 @@ static int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             const unsigned total = (unsigned)pl->tgx;
             pl->tblocks = (int)(((total + 7u) / 8u) * 8u);
             if (pl->tblocks > resident) pl->tblocks = resident >= 8 ? resident / 8 * 8 : 8;
+            c->plan_T = pl->T; c->plan_LY = pl->LY; c->plan_ntx = pl->ntx; c->plan_cpi = pl->tcpi;
+            c->plan_blocks = pl->tblocks;
             // the reference's non-zero link test matters only when a phase cannot diffuse
             pl->guard = c->lut_guard;
         }

@@ -552,9 +552,16 @@ int main(int argc, char **argv)
             st.serve_pending = true;
             const int nx = st.W * o.MeshIncreaseX, ny = st.H * o.MeshIncreaseY;
             // default: enough slots for a stack of ~16 Mi cells (a 128^2 image is 1 strip x few chunks: the
-            // chip needs about a thousand of them in flight)
-            int slots = batch_size > 0 ? batch_size : (int)std::max<long long>(1, (16ll << 20) / ((long long)nx * ny));
-            slots = std::min(slots, 4096);
+            // chip needs about a thousand of them in flight); for long runs of small images ~64 Mi cells,
+            // where every wave sweeps a whole image with nothing recomputed (128^2: 1 347 against
+            // 1 113 G cells*iter/s) -- only when the images outnumber the slots several times, or the
+            // stream would spend its time draining
+            const long long cells = (long long)nx * ny;
+            const long long per_dev = (count + (long long)std::max<size_t>(1, devices.size()) - 1) / (long long)std::max<size_t>(1, devices.size());
+            const long long big = (64ll << 20) / cells, small = std::max<long long>(1, (16ll << 20) / cells);
+            long long want = batch_size > 0 ? batch_size : (big >= 1 && per_dev >= 3 * big ? big : small);
+            want = std::min<long long>(want, std::max<long long>(1, per_dev));
+            const int slots = (int)std::min<long long>(want, 4096);
             if (deff_create_batch(dev, nx, ny, slots, &st.ctx) != DEFF_OK) {
                 std::fprintf(stderr, "deff2d: %s\n", deff_last_error());
                 failed = true;

@@ -65,6 +65,15 @@ class Solver:
     def set_tuning(self, key, value):
         check(self._L.deff_set_tuning(self._ctx, key.encode(), int(value)))
 
+    def plan(self):
+        """What the temporally blocked kernel's last launch plan chose (zeros before any sweep)."""
+        out = {}
+        for key in ("tb_T", "tb_LY", "tb_strips", "tb_chunks_per_image", "tb_blocks"):
+            v = C.c_int()
+            check(self._L.deff_get_plan(self._ctx, key.encode(), C.byref(v)))
+            out[key] = v.value
+        return out
+
     # -- image / assembly -------------------------------------------------
     def set_image(self, pix, ampX=1, ampY=1):
         pix = np.ascontiguousarray(pix, dtype=np.uint8)

@@ -77,6 +77,9 @@ int deff_set_kernel(deff_ctx *ctx, int kernel);
 int deff_get_kernel(const deff_ctx *ctx, int *kernel_in_use);
 /* tuning knob (rows marched per workgroup etc.); 0 restores the default */
 int deff_set_tuning(deff_ctx *ctx, const char *key, int value);
+/* what the last launch plan of the temporally blocked kernel chose: "tb_T", "tb_LY" (rows per chunk),
+ * "tb_strips", "tb_chunks_per_image", "tb_blocks" (workgroups launched); 0 before any sweep */
+int deff_get_plan(deff_ctx *ctx, const char *key, int *value);
 
 /* ---- image -> phases: replaces the mask->D loops cuh:1988-2000 (2-phase),
  *      cuh:1518-1529 (3-phase) and the synthetic generator of SURVEY.md 8d */

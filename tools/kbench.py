@@ -40,8 +40,10 @@ def main():
         for var, s, times, nimg in solvers:
             best, med = min(times), sorted(times)[len(times) // 2]
             rate = nimg * n * n / (med * 1e-3) / 1e6
+            pl = s.plan()
             print(f"n={n:6d} {var:40s} med {med*1e3:9.2f} us  min {best*1e3:9.2f} us  "
-                  f"{rate:10.0f} Mcells*iter/s  {rate*64/1e3:8.0f} GB/s@64B  frac {rate*64/8e6:.3f}", flush=True)
+                  f"{rate:10.0f} Mcells*iter/s  frac@64B {rate*64/8e6:.3f}  "
+                  f"T={pl['tb_T']} LY={pl['tb_LY']} strips={pl['tb_strips']} cpi={pl['tb_chunks_per_image']}", flush=True)
             s.close()
 
 

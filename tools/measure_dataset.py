@@ -26,7 +26,11 @@ with tempfile.TemporaryDirectory() as d:
     open(os.path.join(d, "input.txt"), "w").write(
         "Input File:\nPhases: 2\nDs: 1e-3\nDf: 1\nMeshAmpX: 1\nMeshAmpY: 1\nCR: 1\nCL: 0\nOutputName: out.csv\n"
         f"printCMap: 0\nConvergence: 1e-6\nMaxIter: 5e5\nVerbose: 0\nRunBatch: 1\nNumImages: {N}\n")
-    for label, extra in (("grouped", []), ("one_at_a_time", ["--batch-size", "1"])):
+    runs = [("grouped", [])]
+    if N >= 12288:
+        runs.append(("grouped_1024_slots", ["--batch-size", "1024"]))
+    runs.append(("one_at_a_time", ["--batch-size", "1"]))
+    for label, extra in runs:
         if label == "one_at_a_time" and N > 64:
             open(os.path.join(d, "input.txt"), "a").write("NumImages: 64\n")      # a later key wins: bounded sample
         t0 = time.perf_counter()
