@@ -1,0 +1,115 @@
+// ubench.hip -- instruction-rate microbenchmarks on gfx950 (diagnostics for DESIGN.md's kernel model):
+// how many clocks a wave64 FP64 add / mul / fma, a DPP move and a ds_read_b64 occupy their unit.
+// Each kernel runs `iters` iterations of 8 independent chains per lane; all waves of the chip busy.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_valu(double *out, int iters, double a, double b)
+{
+    double v0 = threadIdx.x, v1 = v0 + 1, v2 = v0 + 2, v3 = v0 + 3, v4 = v0 + 4, v5 = v0 + 5, v6 = v0 + 6, v7 = v0 + 7;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (OP == 0) { v0 += a; v1 += a; v2 += a; v3 += a; v4 += a; v5 += a; v6 += a; v7 += a; }
+            if (OP == 1) { v0 *= b; v1 *= b; v2 *= b; v3 *= b; v4 *= b; v5 *= b; v6 *= b; v7 *= b; }
+            if (OP == 2) {
+                v0 = __builtin_fma(v0, b, a); v1 = __builtin_fma(v1, b, a); v2 = __builtin_fma(v2, b, a); v3 = __builtin_fma(v3, b, a);
+                v4 = __builtin_fma(v4, b, a); v5 = __builtin_fma(v5, b, a); v6 = __builtin_fma(v6, b, a); v7 = __builtin_fma(v7, b, a);
+            }
+            if (OP == 3) {   // one dependent chain only: exposes the latency of a dependent FP64 op
+                v0 += a; v0 *= b; v0 += a; v0 *= b; v0 += a; v0 *= b; v0 += a; v0 *= b;
+            }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;
+}
+
+__global__ __launch_bounds__(256) void k_dpp(int *out, int iters)
+{
+    int v0 = threadIdx.x, v1 = v0 + 1, v2 = v0 + 2, v3 = v0 + 3, v4 = v0 + 4, v5 = v0 + 5, v6 = v0 + 6, v7 = v0 + 7;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v0 = __builtin_amdgcn_update_dpp(0, v0, 0x138, 0xf, 0xf, true); v1 = __builtin_amdgcn_update_dpp(0, v1, 0x130, 0xf, 0xf, true);
+            v2 = __builtin_amdgcn_update_dpp(0, v2, 0x138, 0xf, 0xf, true); v3 = __builtin_amdgcn_update_dpp(0, v3, 0x130, 0xf, 0xf, true);
+            v4 = __builtin_amdgcn_update_dpp(0, v4, 0x138, 0xf, 0xf, true); v5 = __builtin_amdgcn_update_dpp(0, v5, 0x130, 0xf, 0xf, true);
+            v6 = __builtin_amdgcn_update_dpp(0, v6, 0x138, 0xf, 0xf, true); v7 = __builtin_amdgcn_update_dpp(0, v7, 0x130, 0xf, 0xf, true);
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;
+}
+
+// 8 ds_read_b64 per unrolled step at lane-dependent addresses (MODE 0: consecutive 8-B words, MODE 1:
+// a pseudo-random row of a 512-row table, like the row dictionary; MODE 2: all lanes the same word)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_lds(double *out, int iters)
+{
+    __shared__ double tab[8 * 520];
+    for (int i = threadIdx.x; i < 8 * 520; i += 256) tab[i] = i;
+    __syncthreads();
+    unsigned idx = MODE == 0 ? (threadIdx.x & 63) : (MODE == 1 ? (threadIdx.x * 2654435761u >> 23) & 511 : 7);
+    double s = 0;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double *p = tab + idx;
+            double a0 = p[0], a1 = p[520], a2 = p[1040], a3 = p[1560], a4 = p[2080], a5 = p[2600], a6 = p[3120], a7 = p[3640];
+            s += a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+            idx = (idx + (unsigned)(s == 12345.0)) & 511;      // keeps the loads in the loop, never true
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <class F>
+static double time_ms(F launch)
+{
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    launch();
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    launch();
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms;
+}
+
+int main()
+{
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    const double ghz = prop.clockRate * 1e-6;
+    printf("%s: %d CUs, %.2f GHz\n", prop.gcnArchName, cus, ghz);
+    double *out;
+    CHECK(hipMalloc(&out, sizeof(double) * 256 * cus * 8));
+    const int iters = 20000;
+    for (int wg_per_cu : {1, 2, 4}) {                       // 4 / 8 / 16 waves per CU = 1 / 2 / 4 per SIMD
+        const int blocks = cus * wg_per_cu;
+        const double waves_per_simd = wg_per_cu;            // 256 threads = 4 waves = 1 per SIMD
+        auto report = [&](const char *name, double ms, double instr_per_iter) {
+            // wave-instructions issued per SIMD = waves_per_simd * iters * instr_per_iter
+            const double clks = ms * 1e-3 * ghz * 1e9;
+            printf("  %-34s %d wave/SIMD: %8.3f ms  %6.2f clocks per wave-instruction per SIMD\n", name, wg_per_cu, ms,
+                   clks / (waves_per_simd * iters * instr_per_iter));
+        };
+        report("v_add_f64 (8 chains)", time_ms([&] { hipLaunchKernelGGL(k_valu<0>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.5, 1.0000001); }), 32);
+        report("v_mul_f64 (8 chains)", time_ms([&] { hipLaunchKernelGGL(k_valu<1>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.5, 1.0000001); }), 32);
+        report("v_fma_f64 (8 chains)", time_ms([&] { hipLaunchKernelGGL(k_valu<2>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.5, 1.0000001); }), 32);
+        report("add/mul f64, ONE dependent chain", time_ms([&] { hipLaunchKernelGGL(k_valu<3>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.5, 1.0000001); }), 32);
+        report("v_mov_b32_dpp wave_shr/shl", time_ms([&] { hipLaunchKernelGGL(k_dpp, dim3(blocks), dim3(256), 0, 0, (int *)out, iters); }), 32);
+        report("ds_read_b64 consecutive", time_ms([&] { hipLaunchKernelGGL(k_lds<0>, dim3(blocks), dim3(256), 0, 0, out, iters); }), 32);
+        report("ds_read_b64 random rows", time_ms([&] { hipLaunchKernelGGL(k_lds<1>, dim3(blocks), dim3(256), 0, 0, out, iters); }), 32);
+        report("ds_read_b64 broadcast", time_ms([&] { hipLaunchKernelGGL(k_lds<2>, dim3(blocks), dim3(256), 0, 0, out, iters); }), 32);
+    }
+    CHECK(hipFree(out));
+    return 0;
+}
