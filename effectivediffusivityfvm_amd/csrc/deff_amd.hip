@@ -985,7 +985,9 @@ static int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
                     const int cpi_max = (int)(((long)k * resident * 4) / ((long)pl->ntx * c->nimg));
                     if (cpi_max < 1) continue;
                     int ly = (c->own_h + cpi_max - 1) / cpi_max;
-                    if (ly < 1) ly = 1;
+                    // chunks shorter than the pipeline is deep lose more to fill/drain than the model
+                    // says (1024^2, T=4: 3-row chunks 254 G, 4..6-row chunks 295 G cells*iter/s)
+                    if (ly < T) ly = T;
                     const int cpi = (c->own_h + ly - 1) / ly;
                     const long cost = (long)k * (ly + T + ((cpi > 1 || !top_wall) ? T : 0) + 8);
                     if (best_cost < 0 || cost < best_cost) { best_cost = cost; LY = ly; }
