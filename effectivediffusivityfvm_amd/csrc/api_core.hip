@@ -1,0 +1,619 @@
+// api_core.hip -- solver context and C ABI (include/deff_amd.h) of the
+// MI355X-native effective-diffusivity hot path.  Host side of the path the
+// reference implements in Deff2DGPU/Deff2D.cuh: DiscretizeMatrix2D (cuh:815-902),
+// initializeGPU/unInitializeGPU (cuh:904-1021), JacobiGPU (cuh:1163-1314).
+//
+// Design: one context per GPU owns every buffer and a private
+// HIP stream; the image is uploaded as bytes (1 B/pixel) and everything else is
+// produced on the device; sweeps are enqueued back to back with pointer
+// ping-pong (no per-sweep sync or D2D copy, unlike cuh:1239/cuh:1281); a
+// convergence check moves 16*ny bytes, not the field (cuh:1245).
+#include "ctx.hpp"
+#include "driver/jpeg_gray.hpp"
+#include "flood_fill.hpp"
+
+// ------------------------------------------------------------- errors -----
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ---------------------------------------------------------- library -------
+
+extern "C" const char *deff_version(void) { return "deff_amd 0.1 (gfx950)"; }
+extern "C" const char *deff_last_error(void) { return g_err; }
+extern "C" const char *deff_error_string(int code)
+{
+    switch (code) {
+    case DEFF_OK: return "ok";
+    case DEFF_EINVAL: return "invalid argument";
+    case DEFF_EHIP: return "HIP runtime error";
+    case DEFF_ENOMEM: return "out of memory";
+    case DEFF_ENODEV: return "no usable device";
+    case DEFF_ESTATE: return "system or field not set";
+    case DEFF_ECOMM: return "RCCL error";
+    default: return "unknown error";
+    }
+}
+
+extern "C" int deff_device_count(int *count)
+try {
+    if (!count) return fail(DEFF_EINVAL, "count is NULL");
+    int k = 0;
+    hipError_t e = hipGetDeviceCount(&k);
+    if (e != hipSuccess) { *count = 0; return fail(DEFF_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = k;
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+// -------------------------------------------------------- lifecycle -------
+
+extern "C" int deff_create(int device, int nx, int ny, deff_ctx **out)
+try {
+    return deff_create_batch(device, nx, ny, 1, out);
+}
+DEFF_API_CATCH
+
+extern "C" int deff_create_batch(int device, int nx, int ny, int nimg, deff_ctx **out)
+try {
+    if (!out) return fail(DEFF_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (nx < 2 || ny < 2) return fail(DEFF_EINVAL, "mesh must be at least 2x2 (got %dx%d)", nx, ny);
+    if (nimg < 1) return fail(DEFF_EINVAL, "batch size must be >= 1 (got %d)", nimg);
+    if ((size_t)nx * (size_t)ny * (size_t)nimg > (size_t)1 << 31 || (long long)ny * nimg > (1ll << 30))
+        return fail(DEFF_EINVAL, "%d image(s) of %dx%d exceed 2^31 cells", nimg, nx, ny);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(DEFF_ENODEV, "no HIP device (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(DEFF_EINVAL, "device %d out of range [0,%d)", device, count);
+
+    deff_ctx *c = new (std::nothrow) deff_ctx();
+    if (!c) return fail(DEFF_ENOMEM, "host allocation failed");
+    c->device = device;
+    c->nx = nx; c->ny = ny; c->nimg = nimg; c->rows = nimg * ny;
+    c->n_img = (size_t)nx * ny; c->n = c->n_img * nimg;
+    c->active_h.assign(nimg, 1); c->buf_of.assign(nimg, 0);
+    c->mesh_ny = ny; c->own_h = ny;
+    c->dx = 1.0 / nx;           // cuh:1910-1911: the domain is always the unit square
+    c->dy = 1.0 / ny;
+    int rc = DEFF_OK;
+    do {
+        if ((rc = use_device(c)) != DEFF_OK) break;
+        hipError_t he;
+        if ((he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+            (he = hipEventCreate(&c->ev0)) != hipSuccess || (he = hipEventCreate(&c->ev1)) != hipSuccess) {
+            rc = fail(DEFF_EHIP, "stream/event creation failed: %s", hipGetErrorString(he));
+            break;
+        }
+        if ((rc = dev_alloc(&c->x[0], c->n)) != DEFF_OK) break;
+        if ((rc = dev_alloc(&c->x[1], c->n)) != DEFF_OK) break;
+        // the reference zero-fills its device arrays (cuh:946-973)
+        if (hipMemsetAsync(c->x[0], 0, sizeof(double) * c->n, c->stream) != hipSuccess ||
+            hipMemsetAsync(c->x[1], 0, sizeof(double) * c->n, c->stream) != hipSuccess) {
+            rc = fail(DEFF_EHIP, "memset failed");
+            break;
+        }
+    } while (0);
+    if (rc != DEFF_OK) { deff_destroy(c); return rc; }
+    *out = c;
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+extern "C" int deff_destroy(deff_ctx *c)
+try {
+    if (!c) return DEFF_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *bufs[] = {c->pix, c->a0, c->c0, c->aW, c->aE, c->aS, c->aN, c->b, c->code, c->lut,
+                    c->Dl, c->Dr, c->mf, c->x[0], c->x[1], c->scratch, c->active};
+    for (void *p : bufs) if (p) (void)hipFree(p);
+    if (c->mf_host) (void)hipHostFree(c->mf_host);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;                      // no hipDeviceReset (the reference resets per image, cuh:1015)
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+extern "C" int deff_mesh(const deff_ctx *c, int *nx, int *ny, double *dx, double *dy)
+try {
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    if (nx) *nx = c->nx;
+    if (ny) *ny = c->ny;
+    if (dx) *dx = c->dx;
+    if (dy) *dy = c->dy;
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+extern "C" int deff_batch_size(const deff_ctx *c, int *nimg)
+try {
+    if (!c || !nimg) return fail(DEFF_EINVAL, "NULL argument");
+    *nimg = c->nimg;
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+// All images iterate again and their newest field is in x[cur] (after a new guess / system).
+void reset_batch_state(deff_ctx *c)
+{
+    c->active_h.assign(c->nimg, 1);
+    c->buf_of.assign(c->nimg, (uint8_t)c->cur);
+    c->masked = false;
+}
+
+extern "C" int deff_set_kernel(deff_ctx *c, int kernel)
+try {
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    if (kernel < DEFF_KERNEL_AUTO || kernel > DEFF_KERNEL_MATFREE_TB)
+        return fail(DEFF_EINVAL, "unknown kernel id %d", kernel);
+    c->kernel = kernel;
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+// Which kernel a sweep will use, given what has been assembled.
+int resolve_kernel(const deff_ctx *c, int *k)
+{
+    int want = c->kernel;
+    if (want == DEFF_KERNEL_AUTO) want = c->have_matfree ? DEFF_KERNEL_MATFREE_TB : DEFF_KERNEL_EXPLICIT;
+    if (want == DEFF_KERNEL_MATFREE || want == DEFF_KERNEL_MATFREE_TB) {
+        if (!c->have_matfree) {
+            // an explicit system without a usable row dictionary stays on the explicit kernels
+            if (!c->have_explicit) return fail(DEFF_ESTATE, "no system assembled");
+            want = (c->nx & 1) ? DEFF_KERNEL_SCALAR : DEFF_KERNEL_EXPLICIT;
+            *k = want;
+            return DEFF_OK;
+        }
+        // the temporally blocked kernel needs 16-B aligned strips (even nx) and a few rows to stream
+        if (want == DEFF_KERNEL_MATFREE_TB && ((c->nx & 1) || c->ny < 8)) want = DEFF_KERNEL_MATFREE;
+    } else {
+        if (!c->have_explicit && !c->have_matfree) return fail(DEFF_ESTATE, "no system assembled");
+        if (want == DEFF_KERNEL_EXPLICIT && (c->nx & 1)) want = DEFF_KERNEL_SCALAR;   // 16-B rows need even nx
+    }
+    *k = want;
+    return DEFF_OK;
+}
+
+extern "C" int deff_get_kernel(const deff_ctx *c, int *k)
+try {
+    if (!c || !k) return fail(DEFF_EINVAL, "NULL argument");
+    return resolve_kernel(c, k);
+}
+DEFF_API_CATCH
+
+extern "C" int deff_set_tuning(deff_ctx *c, const char *key, int value)
+try {
+    if (!c || !key) return fail(DEFF_EINVAL, "NULL argument");
+    if (value < 0) return fail(DEFF_EINVAL, "tuning value must be >= 0");
+    if (!strcmp(key, "rows_explicit")) c->rows_explicit = value;
+    else if (!strcmp(key, "rows_matfree")) c->rows_matfree = value;
+    else if (!strcmp(key, "wg_matfree")) c->wg_matfree = (value + 7) / 8 * 8;
+    else if (!strcmp(key, "nt_explicit")) c->nt_explicit = value ? 1 : 0;
+    else if (!strcmp(key, "serpentine")) c->serpentine = value ? 1 : 0;
+    else if (!strcmp(key, "tb_T")) c->tb_T = value;
+    else if (!strcmp(key, "tb_LY")) c->tb_LY = value;
+    else if (!strcmp(key, "dict")) c->dict_enabled = value ? 1 : 0;
+    else if (!strcmp(key, "tb_xmajor")) c->tb_xmajor = value ? 1 : 0;
+    else if (!strcmp(key, "tb_wall_halo")) c->tb_wall_halo = value > 2 ? 2 : value;
+    else if (!strcmp(key, "tb_wg")) c->tb_wg = (value + 7) / 8 * 8;
+    else return fail(DEFF_EINVAL, "unknown tuning key '%s'", key);
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+// What the last plan of the temporally blocked kernel chose (0 before any sweep ran on it).
+extern "C" int deff_get_plan(deff_ctx *c, const char *key, int *value)
+try {
+    if (!c || !key || !value) return fail(DEFF_EINVAL, "NULL argument");
+    if (!strcmp(key, "tb_T")) *value = c->plan_T;
+    else if (!strcmp(key, "tb_LY")) *value = c->plan_LY;
+    else if (!strcmp(key, "tb_strips")) *value = c->plan_ntx;
+    else if (!strcmp(key, "tb_chunks_per_image")) *value = c->plan_cpi;
+    else if (!strcmp(key, "tb_blocks")) *value = c->plan_blocks;
+    else return fail(DEFF_EINVAL, "unknown plan key '%s'", key);
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+// ------------------------------------------------------------ image -------
+
+int image_shape(deff_ctx *c, int W, int H, int ampX, int ampY)
+{
+    if (W < 1 || H < 1 || ampX < 1 || ampY < 1)            // cuh:1901-1904
+        return fail(DEFF_EINVAL, "image %dx%d / mesh amplification %dx%d invalid", W, H, ampX, ampY);
+    if ((long long)W * ampX != c->nx || (long long)H * ampY != c->ny)
+        return fail(DEFF_EINVAL, "image %dx%d x amp %dx%d does not match mesh %dx%d", W, H, ampX, ampY,
+                    c->nx, c->ny);
+    if (c->pix && (c->W != W || c->H != H)) { HIP_TRY(hipFree(c->pix)); c->pix = nullptr; }
+    TRY(dev_alloc(&c->pix, (size_t)W * H * c->nimg));
+    c->W = W; c->H = H; c->ampX = ampX; c->ampY = ampY;
+    return DEFF_OK;
+}
+
+extern "C" int deff_set_image(deff_ctx *c, const uint8_t *pix, int W, int H, int ampX, int ampY)
+try {
+    if (!c || !pix) return fail(DEFF_EINVAL, "NULL argument");
+    TRY(use_device(c));
+    TRY(image_shape(c, W, H, ampX, ampY));
+    HIP_TRY(hipMemcpyAsync(c->pix, pix, (size_t)W * H * c->nimg, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_image = true;
+    c->have_matfree = false;
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+extern "C" int deff_synth_image(deff_ctx *c, uint64_t seed, uint64_t img)
+try {
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    TRY(use_device(c));
+    TRY(image_shape(c, c->nx, c->ny, 1, 1));
+    // stacked rows continue the per-pixel key, so a batch holds images img, img+1, ...
+    hipLaunchKernelGGL(k_synth_mask, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->nx, c->rows,
+                       seed, img);
+    HIP_TRY(hipGetLastError());
+    c->have_image = true;
+    c->have_matfree = false;
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+extern "C" int deff_get_image(deff_ctx *c, uint8_t *pix)
+try {
+    if (!c || !pix) return fail(DEFF_EINVAL, "NULL argument");
+    if (!c->have_image) return fail(DEFF_ESTATE, "no image set");
+    TRY(use_device(c));
+    HIP_TRY(hipMemcpyAsync(pix, c->pix, (size_t)c->W * c->H * c->nimg, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+// --------------------------------------------------------- assembly -------
+
+// Row dictionary of the native 2-phase system, enumerated a priori: for every position class and
+// every own/W/E/S/N phase pattern the matrix row fvm_row() produces -- built on the host with the
+// same routine the device assembly uses, so it holds the very same doubles.  Row 0 = zeros.
+void build_lut_rows(deff_ctx *c, double Ds, double Df, double CL, double CR)
+{
+    c->lut_nrows = LUT_NATIVE_ROWS;
+    c->lut_rows.assign((size_t)c->lut_nrows * 6, 0.0);
+    for (int ycls = 0; ycls < 3; ++ycls)
+        for (int xcls = 0; xcls < 3; ++xcls)
+            for (int code = 0; code < 32; ++code) {
+                auto D = [&](int bit) { return ((code >> bit) & 1) ? Ds : Df; };
+                const FvmRow r = fvm_row(D(0), D(1), D(2), D(3), D(4), xcls, ycls, c->dx, c->dy, CL, CR);
+                double *row = &c->lut_rows[(size_t)(1 + (ycls * 3 + xcls) * 32 + code) * 6];
+                row[0] = r.a0; row[1] = r.aW; row[2] = r.aE; row[3] = r.aS; row[4] = r.aN; row[5] = r.b;
+            }
+    c->lut_allb = false;
+    c->lut_omega = NAN;
+}
+
+// Device tables for a given omega: plane 0 holds c0 = omega / A0 (the reference divides w by
+// A[p*5+0] first, cuh:89), the other planes the links and b.
+int upload_lut(deff_ctx *c, double omega)
+{
+    if (c->lut_omega == omega) return DEFF_OK;
+    std::vector<double> t(LUT_DOUBLES, 0.0);
+    bool guard = false;
+    for (int k = 1; k < c->lut_nrows; ++k) {
+        const double *row = &c->lut_rows[(size_t)k * 6];
+        const double c0 = omega / row[0];
+        if (!std::isfinite(c0)) guard = true;
+        t[k] = c0;
+        for (int pl = 1; pl < LUT_PLANES; ++pl) t[(size_t)pl * LUT_PLANE_STRIDE + k] = row[pl];
+    }
+    TRY(dev_alloc(&c->lut, (size_t)LUT_DOUBLES));
+    HIP_TRY(hipMemcpyAsync(c->lut, t.data(), sizeof(double) * LUT_DOUBLES, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // `t` goes out of scope
+    // With every c0 finite the field stays finite, a zero link then contributes exactly +-0 and the
+    // reference's `A != 0` test (cuh:77) cannot change a bit; otherwise (a phase that cannot
+    // diffuse made a singular row) the guarded kernels keep its skip semantics.
+    c->lut_guard = guard;
+    c->lut_omega = omega;
+    return DEFF_OK;
+}
+
+extern "C" int deff_assemble_2phase(deff_ctx *c, double Ds, double Df, double CL, double CR)
+try {
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    if (!c->have_image) return fail(DEFF_ESTATE, "deff_assemble_2phase needs an image");
+    TRY(use_device(c));
+    TRY(ensure_walls(c));
+    c->CL = CL; c->CR = CR;
+    hipLaunchKernelGGL(k_wall_D_2phase, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, c->pix, c->W,
+                       c->ampX, c->ampY, c->nx, c->ny, c->rows, Df, Ds, c->Dl, c->Dr);
+    HIP_TRY(hipGetLastError());
+    c->have_walls = true;
+
+    // matrix-free form: 1 byte per cell + lookup tables
+    TRY(dev_alloc(&c->code, c->n));
+    c->dict_tried = false;
+    hipLaunchKernelGGL(k_phase_codes, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->W, c->ampX,
+                       c->ampY, c->nx, c->ny, c->rows, c->dom_lo, c->mesh_ny, c->code);
+    HIP_TRY(hipGetLastError());
+    build_lut_rows(c, Ds, Df, CL, CR);
+    c->have_matfree = true;
+
+    // the explicit SoA planes are built on demand (explicit_from_image)
+    c->Ds = Ds; c->Df = Df;
+    c->have_explicit = false;
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+// Explicit SoA planes for the native 2-phase system: D from the pixels
+// (cuh:1988-2000), then the general assembly.  Only needed when an explicit
+// kernel is selected or the coefficients are exported.
+int explicit_from_image(deff_ctx *c)
+{
+    if (c->have_explicit) return DEFF_OK;
+    if (!c->have_matfree) return fail(DEFF_ESTATE, "no system assembled");
+    TRY(ensure_explicit(c));
+    TRY(ensure_scratch(c, sizeof(double) * c->n));
+    double *D = (double *)c->scratch;
+    hipLaunchKernelGGL(k_fill_D_2phase, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->W, c->ampX,
+                       c->ampY, c->nx, c->ny, c->rows, c->Df, c->Ds, D);
+    hipLaunchKernelGGL(k_assemble_from_D, dim3(grid_for(c->n)), dim3(256), 0, c->stream, D,
+                       (const unsigned int *)nullptr, c->nx, c->ny, c->rows, c->dx, c->dy, c->CL, c->CR,
+                       soa_of(c));
+    HIP_TRY(hipGetLastError());
+    c->have_explicit = true;
+    c->c0_omega = NAN;
+    return DEFF_OK;
+}
+
+// 3-phase system (SingleSim3Phase cuh:1509-1535 / cuh:1558-1586): D from the three pixel
+// classes on the device, then DiscretizeMatrix2D_ImpSolid with the caller's Grid (the output of
+// deff_flood_fill on `pixel > 200`), or plain DiscretizeMatrix2D when Grid is NULL.  Explicit
+// coefficient planes: identity rows and zero-diffusivity links need the guarded general kernel.
+extern "C" int deff_assemble_3phase(deff_ctx *c, double Ds, double Df, double Dg, const unsigned int *Grid,
+                                    double CL, double CR)
+try {
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    if (!c->have_image) return fail(DEFF_ESTATE, "deff_assemble_3phase needs an image");
+    TRY(use_device(c));
+    TRY(ensure_explicit(c));
+    TRY(ensure_walls(c));
+    const size_t bytes = sizeof(double) * c->n + (Grid ? sizeof(unsigned int) * c->n : 0);
+    TRY(ensure_scratch(c, bytes));
+    double *dD = (double *)c->scratch;
+    unsigned int *dG = Grid ? (unsigned int *)((char *)c->scratch + sizeof(double) * c->n) : nullptr;
+    if (Grid) HIP_TRY(hipMemcpyAsync(dG, Grid, sizeof(unsigned int) * c->n, hipMemcpyHostToDevice, c->stream));
+    c->CL = CL; c->CR = CR;
+    hipLaunchKernelGGL(k_fill_D_3phase, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->W, c->ampX,
+                       c->ampY, c->nx, c->ny, c->rows, Df, Ds, Dg, dD);
+    hipLaunchKernelGGL(k_assemble_from_D, dim3(grid_for(c->n)), dim3(256), 0, c->stream, dD, dG, c->nx,
+                       c->ny, c->rows, c->dx, c->dy, CL, CR, soa_of(c));
+    hipLaunchKernelGGL(k_wall_D_from_D, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, dD, c->nx,
+                       c->rows, c->Dl, c->Dr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));        // Grid may be freed by the caller
+    c->have_explicit = true; c->c0_omega = NAN; c->have_walls = true;
+    c->have_matfree = false; c->dict_tried = false;
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+// FloodFill, cuh:557-713 (host, see flood_fill.hpp).  Grid: 1 = solid on entry; unreachable
+// non-solid cells are set to 2; *path_flag receives PathFlag.
+extern "C" int deff_flood_fill(unsigned int *Grid, int nx, int ny, int *path_flag)
+try {
+    if (!Grid || nx < 1 || ny < 1) return fail(DEFF_EINVAL, "bad flood-fill arguments");
+    const int flag = flood_fill(Grid, nx, ny);
+    if (path_flag) *path_flag = flag;
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+// Grayscale JPEG -> bytes, the reference's readImage (cuh:327-345: stbi_load(name,&w,&h,&n,1)).
+// *pix is malloc'ed (release with deff_free); *nChannels is the file's component count and is set
+// even when the call fails because the image is not single-channel (the reference's check).
+extern "C" int deff_load_jpeg_gray(const char *path, uint8_t **pix, int *W, int *H, int *nChannels)
+try {
+    if (!path || !pix || !W || !H) return fail(DEFF_EINVAL, "NULL argument");
+    std::vector<uint8_t> buf;
+    std::string err;
+    int n = 0;
+    *pix = nullptr;
+    const bool ok = jpeg::load_gray(path, buf, *W, *H, n, err);
+    if (nChannels) *nChannels = n;
+    if (!ok) return fail(DEFF_EINVAL, "%s: %s", path, err.c_str());
+    *pix = (uint8_t *)malloc(buf.size());
+    if (!*pix) return fail(DEFF_ENOMEM, "host allocation failed");
+    memcpy(*pix, buf.data(), buf.size());
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+extern "C" void deff_free(void *p) { free(p); }
+
+// Host -> device in bounded chunks through the scratch buffer.
+static const size_t CHUNK_CELLS = (size_t)1 << 22;   // 4 Mi cells
+
+extern "C" int deff_assemble_from_D(deff_ctx *c, const double *D, const unsigned int *Grid, double CL,
+                                    double CR)
+try {
+    if (!c || !D) return fail(DEFF_EINVAL, "NULL argument");
+    TRY(use_device(c));
+    TRY(ensure_explicit(c));
+    TRY(ensure_walls(c));
+    const size_t bytes = sizeof(double) * c->n + (Grid ? sizeof(unsigned int) * c->n : 0);
+    TRY(ensure_scratch(c, bytes));
+    double *dD = (double *)c->scratch;
+    unsigned int *dG = Grid ? (unsigned int *)((char *)c->scratch + sizeof(double) * c->n) : nullptr;
+    HIP_TRY(hipMemcpyAsync(dD, D, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
+    if (Grid) HIP_TRY(hipMemcpyAsync(dG, Grid, sizeof(unsigned int) * c->n, hipMemcpyHostToDevice, c->stream));
+    c->CL = CL; c->CR = CR;
+    hipLaunchKernelGGL(k_assemble_from_D, dim3(grid_for(c->n)), dim3(256), 0, c->stream, dD, dG, c->nx,
+                       c->ny, c->rows, c->dx, c->dy, CL, CR, soa_of(c));
+    hipLaunchKernelGGL(k_wall_D_from_D, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, dD, c->nx,
+                       c->rows, c->Dl, c->Dr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_explicit = true; c->c0_omega = NAN; c->have_walls = true;
+    c->have_matfree = false; c->dict_tried = false;
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+extern "C" int deff_set_system(deff_ctx *c, const double *A, const double *b, const double *D, double CL,
+                               double CR)
+try {
+    if (!c || !A || !b) return fail(DEFF_EINVAL, "NULL argument");
+    TRY(use_device(c));
+    TRY(ensure_explicit(c));
+    TRY(ensure_scratch(c, sizeof(double) * 5 * CHUNK_CELLS));
+    for (size_t first = 0; first < c->n; first += CHUNK_CELLS) {
+        const size_t cnt = (c->n - first < CHUNK_CELLS) ? c->n - first : CHUNK_CELLS;
+        HIP_TRY(hipMemcpyAsync(c->scratch, A + first * 5, sizeof(double) * 5 * cnt, hipMemcpyHostToDevice,
+                               c->stream));
+        hipLaunchKernelGGL(k_import_aos, dim3(grid_for(cnt)), dim3(256), 0, c->stream,
+                           (const double *)c->scratch, first, cnt, soa_of(c));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(c->b, b, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
+    c->CL = CL; c->CR = CR;
+    c->have_walls = false;
+    if (D) {
+        TRY(ensure_walls(c));
+        // only the first and last column of D are ever read (cuh:1256-1257)
+        for (int i = 0; i < c->rows; ++i) {
+            c->mf_host[i] = D[(size_t)i * c->nx];
+            c->mf_host[c->rows + i] = D[(size_t)(i + 1) * c->nx - 1];
+        }
+        HIP_TRY(hipMemcpyAsync(c->Dl, c->mf_host, sizeof(double) * c->rows, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->Dr, c->mf_host + c->rows, sizeof(double) * c->rows, hipMemcpyHostToDevice,
+                               c->stream));
+        c->have_walls = true;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_explicit = true; c->c0_omega = NAN;
+    c->have_matfree = false; c->dict_tried = false;
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+extern "C" int deff_get_system(deff_ctx *c, double *A, double *b)
+try {
+    if (!c || !A || !b) return fail(DEFF_EINVAL, "NULL argument");
+    TRY(use_device(c));
+    if (c->have_explicit) {
+        TRY(ensure_scratch(c, sizeof(double) * 5 * CHUNK_CELLS));
+        for (size_t first = 0; first < c->n; first += CHUNK_CELLS) {
+            const size_t cnt = (c->n - first < CHUNK_CELLS) ? c->n - first : CHUNK_CELLS;
+            hipLaunchKernelGGL(k_export_aos, dim3(grid_for(cnt)), dim3(256), 0, c->stream, (double *)c->scratch,
+                               first, cnt, soa_of(c));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(A + first * 5, c->scratch, sizeof(double) * 5 * cnt, hipMemcpyDeviceToHost,
+                                   c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(b, c->b, sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return DEFF_OK;
+    }
+    if (c->have_matfree) {
+        // expand the codes through the row dictionary (what the matrix-free kernels "see")
+        std::vector<uint16_t> code(c->n);
+        HIP_TRY(hipMemcpyAsync(code.data(), c->code, sizeof(uint16_t) * c->n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (size_t p = 0; p < c->n; ++p) {
+            const double *row = &c->lut_rows[(size_t)(code[p] >> 3) * 6];
+            for (int k = 0; k < 5; ++k) A[p * 5 + k] = row[k];
+            b[p] = row[5];
+        }
+        return DEFF_OK;
+    }
+    return fail(DEFF_ESTATE, "no system assembled");
+}
+DEFF_API_CATCH
+
+// ------------------------------------------------------------ field -------
+
+extern "C" int deff_init_linear(deff_ctx *c, double CL, double CR)
+try {
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    TRY(use_device(c));
+    hipLaunchKernelGGL(k_init_linear, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->x[c->cur], c->nx,
+                       c->rows, CL, CR);
+    HIP_TRY(hipGetLastError());
+    c->have_field = true;
+    reset_batch_state(c);
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+// After a batch solve the images that converged earlier sit frozen in whichever ping-pong
+// buffer was current at that moment; bring every image's newest field into x[cur].
+int consolidate(deff_ctx *c)
+{
+    if (!c->masked) return DEFF_OK;                  // nothing frozen: every image is current in x[cur]
+    for (int k = 0; k < c->nimg; ++k)
+        if (c->buf_of[k] != (uint8_t)c->cur) {
+            const size_t off = (size_t)k * c->n_img;
+            HIP_TRY(hipMemcpyAsync(c->x[c->cur] + off, c->x[c->buf_of[k]] + off, sizeof(double) * c->n_img,
+                                   hipMemcpyDeviceToDevice, c->stream));
+            c->buf_of[k] = (uint8_t)c->cur;
+        }
+    c->active_h.assign(c->nimg, 1);
+    c->masked = false;
+    return DEFF_OK;
+}
+
+extern "C" int deff_set_field(deff_ctx *c, const double *x)
+try {
+    if (!c || !x) return fail(DEFF_EINVAL, "NULL argument");
+    TRY(use_device(c));
+    HIP_TRY(hipMemcpyAsync(c->x[c->cur], x, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_field = true;
+    reset_batch_state(c);
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+extern "C" int deff_get_field(deff_ctx *c, double *x)
+try {
+    if (!c || !x) return fail(DEFF_EINVAL, "NULL argument");
+    TRY(use_device(c));
+    TRY(consolidate(c));
+    HIP_TRY(hipMemcpyAsync(x, c->x[c->cur], sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+extern "C" int deff_device_field(deff_ctx *c, void **d_x, size_t *pitch)
+try {
+    if (!c || !d_x) return fail(DEFF_EINVAL, "NULL argument");
+    TRY(use_device(c));
+    TRY(consolidate(c));
+    *d_x = c->x[c->cur];
+    if (pitch) *pitch = sizeof(double) * c->nx;
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+extern "C" int deff_synchronize(deff_ctx *c)
+try {
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    TRY(use_device(c));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DEFF_OK;
+}
+DEFF_API_CATCH

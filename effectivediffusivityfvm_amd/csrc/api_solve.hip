@@ -1,0 +1,695 @@
+// api_solve.hip -- launch plans, sweeps and the solve loops of libdeff_amd.so: the host side of
+// JacobiGPU (Deff2DGPU/Deff2D.cuh:1163-1314) for one image, a stack of images and a stream of
+// images through a stack.  See ctx.hpp for the file map, DESIGN.md section 4-6 for the design.
+#include "ctx.hpp"
+#include "kernels_dict.hpp"
+#include "kernels_sweep.hpp"
+#include "kernels_tb.hpp"
+
+// ----------------------------------------------------------- sweeps -------
+
+// Workgroups of the temporally blocked kernel that are resident at once on this device.
+template <int T, int CPL, bool G>
+static int tb_occ(int *per_cu)
+{
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_sweep_matfree_tb<T, CPL, G>, 256, 0));
+    return DEFF_OK;
+}
+
+// Only 2 cells per lane are instantiated: 4 per lane (twice the work per wave, 244 VGPRs,
+// 2 waves per SIMD) measured 20 % slower at 4096^2 -- the kernel needs the wave-level
+// parallelism more than it needs the smaller strip overlap.
+#define TB_DISPATCH(T_, CPL_, G_, CALL)                                                     \
+    do {                                                                                    \
+        const int key_ = (T_) * 10 + ((G_) ? 1 : 0);                                        \
+        switch (key_) {                                                                     \
+        case 10: { CALL(1, 2, false); } break; case 11: { CALL(1, 2, true); } break;       \
+        case 20: { CALL(2, 2, false); } break; case 21: { CALL(2, 2, true); } break;       \
+        case 40: { CALL(4, 2, false); } break; case 41: { CALL(4, 2, true); } break;       \
+        case 60: { CALL(6, 2, false); } break; case 61: { CALL(6, 2, true); } break;       \
+        default: { CALL(8, 2, false); } break; case 81: { CALL(8, 2, true); } break;       \
+        }                                                                                   \
+    } while (0)
+
+static int tb_resident_blocks(const deff_ctx *c, int T, int CPL, bool guard, int *resident)
+{
+    int per_cu = 0, cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+#define OCC_CALL(T_, C_, G_) TRY((tb_occ<T_, C_, G_>(&per_cu)))
+    TB_DISPATCH(T, CPL, guard, OCC_CALL);
+#undef OCC_CALL
+    if (per_cu < 1) per_cu = 1;
+    *resident = per_cu * cus;
+    return DEFF_OK;
+}
+
+static int pick_R(int requested, int dflt)
+{
+    const int r = requested ? requested : dflt;
+    return r >= 8 ? 8 : r >= 4 ? 4 : r >= 2 ? 2 : 1;
+}
+
+static void tile_grid(const deff_ctx *c, int cols_per_block, int rows, SweepPlan *pl)
+{
+    pl->rows = rows;
+    pl->gx = (c->nx + cols_per_block - 1) / cols_per_block;
+    pl->cpi = (c->ny + rows - 1) / rows;               // row tiles never straddle two images
+    pl->gy = pl->cpi * c->nimg;
+    const unsigned total = (unsigned)pl->gx * (unsigned)pl->gy;
+    pl->blocks = (int)(((total + 7u) / 8u) * 8u);      // see xcd_tile()
+}
+
+int default_tb_T(const deff_ctx *c)
+{
+    if (c->n < ((size_t)1 << 22)) return 4;
+    return (c->nimg == 1 && !c->slab && c->n >= ((size_t)1 << 24)) ? 8 : 6;
+}
+
+// Harvest the row dictionary of the explicit system (kernels_dict.hpp).  On success the context
+// also has a matrix-free form (codes + tables); when the system has too many distinct rows it
+// simply keeps running on the explicit kernels.
+static int try_dict(deff_ctx *c)
+{
+    c->dict_tried = true;
+    if (!c->have_explicit || (c->nx & 1)) return DEFF_OK;
+    const size_t S = DICT_SLOTS;
+    const size_t bytes = S * (8 + 4 + 8) + 16 + S * 2 + (size_t)LUT_MAX_ROWS * (8 + 48);
+    TRY(ensure_scratch(c, bytes));
+    char *base = (char *)c->scratch;
+    DictTable t;
+    t.key = (unsigned long long *)base;
+    t.rep = (unsigned long long *)(base + S * 8);
+    t.count = (unsigned int *)(base + S * 16);
+    t.flags = (unsigned int *)(base + S * 20);
+    uint16_t *d_slot2code = (uint16_t *)(base + S * 20 + 16);
+    unsigned long long *d_cells = (unsigned long long *)(base + S * 22 + 16);
+    double *d_rows = (double *)(base + S * 22 + 16 + (size_t)LUT_MAX_ROWS * 8);
+    HIP_TRY(hipMemsetAsync(base, 0, S * 20 + 16, c->stream));
+    const CoefSoA planes = soa_of(c);
+    hipLaunchKernelGGL(k_dict_insert, dim3(grid_for(c->n, 4096)), dim3(256), 0, c->stream, planes, c->n, t);
+    HIP_TRY(hipGetLastError());
+    std::vector<unsigned long long> key(S), rp(S);
+    std::vector<unsigned int> cnt(S);
+    unsigned int flags[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(key.data(), t.key, S * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(rp.data(), t.rep, S * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(cnt.data(), t.count, S * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(flags, t.flags, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (flags[0]) return DEFF_OK;                                 // table overflow: far too many rows
+    struct Ent { unsigned int count; unsigned long long cell; unsigned slot; };
+    std::vector<Ent> ents;
+    for (unsigned sl = 0; sl < S; ++sl)
+        if (key[sl]) ents.push_back({cnt[sl], rp[sl] - 1, sl});
+    if (ents.empty() || (int)ents.size() + 1 > LUT_MAX_ROWS) return DEFF_OK;
+    // most populous rows first: the 32 commonest rows then share one conflict-free LDS bank row
+    std::sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) {
+        return a.count != b.count ? a.count > b.count : a.cell < b.cell;
+    });
+    std::vector<uint16_t> slot2code(S, 0xFFFFu);
+    std::vector<unsigned long long> cells(ents.size());
+    for (size_t k = 0; k < ents.size(); ++k) {
+        slot2code[ents[k].slot] = (uint16_t)((k + 1) * 8);
+        cells[k] = ents[k].cell;
+    }
+    HIP_TRY(hipMemcpyAsync(d_slot2code, slot2code.data(), S * 2, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_cells, cells.data(), cells.size() * 8, hipMemcpyHostToDevice, c->stream));
+    const int nrows = (int)ents.size();
+    hipLaunchKernelGGL(k_dict_gather, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, planes, d_cells, nrows, d_rows);
+    TRY(dev_alloc(&c->code, c->n));
+    hipLaunchKernelGGL(k_dict_encode, dim3(grid_for(c->n, 4096)), dim3(256), 0, c->stream, planes, c->n, c->nx, t,
+                       d_slot2code, c->code);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> rows((size_t)nrows * 6);
+    HIP_TRY(hipMemcpyAsync(rows.data(), d_rows, rows.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(flags, t.flags, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (flags[1]) return DEFF_OK;                                 // hash collision (astronomically unlikely): stay explicit
+    c->lut_nrows = nrows + 1;
+    c->lut_rows.assign((size_t)c->lut_nrows * 6, 0.0);
+    memcpy(&c->lut_rows[6], rows.data(), rows.size() * 8);
+    c->lut_allb = flags[2] != 0;
+    c->lut_omega = NAN;
+    c->have_matfree = true;
+    return DEFF_OK;
+}
+
+int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
+{
+    if (!c->have_field) return fail(DEFF_ESTATE, "no field: call deff_init_linear() or deff_set_field()");
+    // an explicit system (host-assembled, 3-phase, ImpSolid) with few distinct rows also runs matrix-free
+    if (!c->have_matfree && c->have_explicit && !c->dict_tried && c->dict_enabled &&
+        (c->kernel == DEFF_KERNEL_AUTO || c->kernel == DEFF_KERNEL_MATFREE || c->kernel == DEFF_KERNEL_MATFREE_TB))
+        TRY(try_dict(c));
+    TRY(resolve_kernel(c, &pl->kernel));
+    pl->omw = 1.0 - omega;                              // cuh:89 evaluates (1.0 - w) in double
+    if (pl->kernel == DEFF_KERNEL_MATFREE || pl->kernel == DEFF_KERNEL_MATFREE_TB) {
+        TRY(upload_lut(c, omega));
+        if (pl->kernel == DEFF_KERNEL_MATFREE_TB) {
+            // sweeps per pass (measured, G cells*iter/s: 4096^2 T=4 926, T=6 1063, T=8 1106; stacks of
+            // 16 x 1024^2 peak at T=6; 1024^2 alone at T=4)
+            int T = pl->T_override ? pl->T_override : (c->tb_T ? c->tb_T : default_tb_T(c));
+            T = T >= 8 ? 8 : T >= 6 ? 6 : T >= 4 ? 4 : T >= 2 ? 2 : 1;
+            pl->T = T;
+            pl->CPL = 2;
+            // strips of 128 columns overlapping by 2*HW; a mesh wall needs no halo (kernels_tb.hpp)
+            const int hw = (T + 1) & ~1, wout = 64 * pl->CPL - 2 * hw;
+            // placement A: every strip carries its halo, also outside the first column; placement B:
+            // no halo outside a wall (kernels_tb.hpp).  B needs fewer strips for narrow images
+            // (a 128-column image is ONE strip: 2x on dataset batches); where the counts tie, A measured
+            // equal or up to 5 % faster in one process (T = 8 at 4096^2), so B is used only when it wins.
+            const int ntx_a = (c->nx + wout - 1) / wout;
+            const int ntx_b = c->nx <= 64 * pl->CPL ? 1 : (c->nx - 64 * pl->CPL + wout - 1) / wout + 1;
+            const bool use_b = c->tb_wall_halo == 0 ? true : (c->tb_wall_halo == 1 ? false : ntx_b < ntx_a);
+            pl->shift = use_b ? 0 : hw;
+            pl->ntx = use_b ? ntx_b : ntx_a;
+            // Rows per chunk.  Workgroups are persistent, so a pass takes `rounds` tiles per wave slot
+            // (one round = as many wave tiles as are resident at once), and a tile costs its LY rows
+            // + T steps that drain the pipeline + T rows of halo above it unless it starts at the top
+            // wall of its image + a fixed start-up (first loads, measured ~8 row steps).  Pick the
+            // chunks per image minimising rounds x tile cost; for k rounds only the largest chunk
+            // count that fits matters.  (Stacks of small images: 3 072 x 128^2 as whole-image tiles
+            // 1 266 G cells*iter/s against 1 107 G for the 4 x 32-row tiles a halo-blind model picks.)
+            int resident = c->tb_wg;
+            if (!resident) TRY(tb_resident_blocks(c, T, pl->CPL, c->lut_guard, &resident));
+            int LY = c->tb_LY;
+            if (!LY) {
+                long best_cost = -1;
+                const bool top_wall = c->own_lo == 0;              // not a slab with rows above it
+                for (int k = 1; k <= 8; ++k) {
+                    const int cpi_max = (int)(((long)k * resident * 4) / ((long)pl->ntx * c->nimg));
+                    if (cpi_max < 1) continue;
+                    int ly = (c->own_h + cpi_max - 1) / cpi_max;
+                    // chunks shorter than the pipeline is deep lose more to fill/drain than the model
+                    // says (1024^2, T=4: 3-row chunks 254 G, 4..6-row chunks 295 G cells*iter/s)
+                    if (ly < T) ly = T;
+                    const int cpi = (c->own_h + ly - 1) / ly;
+                    const long cost = (long)k * (ly + T + ((cpi > 1 || !top_wall) ? T : 0) + 8);
+                    if (best_cost < 0 || cost < best_cost) { best_cost = cost; LY = ly; }
+                }
+                if (!LY) LY = c->own_h;
+            }
+            if (LY > c->own_h) LY = c->own_h;
+            pl->LY = LY;
+            pl->tcpi = (c->own_h + LY - 1) / LY;
+            pl->tgy = pl->tcpi * c->nimg;
+            pl->tgx = (int)(((long)pl->ntx * pl->tgy + 3) / 4);       // workgroup tiles (4 wave tiles each)
+            const unsigned total = (unsigned)pl->tgx;
+            pl->tblocks = (int)(((total + 7u) / 8u) * 8u);
+            if (pl->tblocks > resident) pl->tblocks = resident >= 8 ? resident / 8 * 8 : 8;
+            c->plan_T = pl->T; c->plan_LY = pl->LY; c->plan_ntx = pl->ntx; c->plan_cpi = pl->tcpi;
+            c->plan_blocks = pl->tblocks;
+            // the reference's non-zero link test matters only when a phase cannot diffuse
+            pl->guard = c->lut_guard;
+        }
+        const int vec = (c->nx & 1) ? 1 : 2;
+        tile_grid(c, 256 * vec, pick_R(c->rows_matfree, c->n >= ((size_t)1 << 21) ? 8 : 2), pl);
+        // persistent grid: a few workgroups per CU walk the tiles (tables loaded once each)
+        const int cap = c->wg_matfree ? c->wg_matfree : 256 * 8;
+        if (pl->blocks > cap) pl->blocks = cap;
+    } else {
+        TRY(explicit_from_image(c));
+        if (c->c0_omega != omega) {
+            hipLaunchKernelGGL(k_make_c0, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->a0, omega, c->c0,
+                               c->n);
+            HIP_TRY(hipGetLastError());
+            c->c0_omega = omega;
+        }
+        if (pl->kernel == DEFF_KERNEL_EXPLICIT)
+            tile_grid(c, 512, pick_R(c->rows_explicit, 1), pl);
+    }
+    return DEFF_OK;
+}
+
+// Enqueue one sweep x[cur] -> x[cur^1] and flip (the reference copies instead, cuh:1281).
+void enqueue_sweep(deff_ctx *c, const SweepPlan &pl)
+{
+    const double *xin = c->x[c->cur];
+    double *xout = c->x[c->cur ^ 1];
+    const CoefConst cf{c->c0, c->aW, c->aE, c->aS, c->aN, c->b};
+    const int flip = c->serpentine ? c->cur : 0;
+    const uint8_t *mask = c->masked ? c->active : nullptr;
+    switch (pl.kernel) {
+    case DEFF_KERNEL_SCALAR:
+        if (c->nt_explicit)
+            hipLaunchKernelGGL(k_sweep_scalar<true>, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
+                               cf, xin, xout, c->nx, c->n, c->n_img, mask, pl.omw);
+        else
+            hipLaunchKernelGGL(k_sweep_scalar<false>, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
+                               cf, xin, xout, c->nx, c->n, c->n_img, mask, pl.omw);
+        break;
+    case DEFF_KERNEL_EXPLICIT: {
+#define LAUNCH_EXPLICIT(R_)                                                                                  \
+    do {                                                                                                    \
+        if (c->nt_explicit)                                                                                 \
+            hipLaunchKernelGGL((k_sweep_explicit<R_, true>), dim3(pl.blocks), dim3(256), 0, c->stream, cf,  \
+                               xin, xout, c->nx, c->ny, c->rows, pl.cpi, mask, pl.gx, pl.gy, flip, pl.omw); \
+        else                                                                                                \
+            hipLaunchKernelGGL((k_sweep_explicit<R_, false>), dim3(pl.blocks), dim3(256), 0, c->stream, cf, \
+                               xin, xout, c->nx, c->ny, c->rows, pl.cpi, mask, pl.gx, pl.gy, flip, pl.omw); \
+    } while (0)
+        switch (pl.rows) {
+        case 1: LAUNCH_EXPLICIT(1); break;
+        case 2: LAUNCH_EXPLICIT(2); break;
+        case 4: LAUNCH_EXPLICIT(4); break;
+        default: LAUNCH_EXPLICIT(8); break;
+        }
+#undef LAUNCH_EXPLICIT
+        break;
+    }
+    default: {
+#define LAUNCH_MATFREE(V_, R_)                                                                               \
+    hipLaunchKernelGGL((k_sweep_matfree<V_, R_>), dim3(pl.blocks), dim3(256), 0, c->stream, c->lut, c->code, \
+                       xin, xout, c->nx, c->ny, c->rows, pl.cpi, mask, pl.gx, pl.gy, flip, c->lut_nrows, pl.omw)
+        if (c->nx & 1) {
+            switch (pl.rows) {
+            case 1: LAUNCH_MATFREE(1, 1); break;
+            case 2: LAUNCH_MATFREE(1, 2); break;
+            case 4: LAUNCH_MATFREE(1, 4); break;
+            default: LAUNCH_MATFREE(1, 8); break;
+            }
+        } else {
+            switch (pl.rows) {
+            case 1: LAUNCH_MATFREE(2, 1); break;
+            case 2: LAUNCH_MATFREE(2, 2); break;
+            case 4: LAUNCH_MATFREE(2, 4); break;
+            default: LAUNCH_MATFREE(2, 8); break;
+            }
+        }
+#undef LAUNCH_MATFREE
+        break;
+    }
+    }
+    c->cur ^= 1;
+}
+
+// One temporally blocked pass: T sweeps, x[cur] -> x[cur^1].
+void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl)
+{
+    const double *xin = c->x[c->cur];
+    double *xout = c->x[c->cur ^ 1];
+    const int flip = c->serpentine ? c->cur : 0;
+    const uint8_t *mask = c->masked ? c->active : nullptr;
+#define LAUNCH_TB(T_, C_, G_)                                                                                  \
+    hipLaunchKernelGGL((k_sweep_matfree_tb<T_, C_, G_>), dim3(pl.tblocks), dim3(256), 0, c->stream, c->lut,    \
+                       c->code, xin, xout, c->nx, c->mesh_ny, c->ny, c->dom_lo, c->own_lo, c->own_h, pl.tcpi, \
+                       mask, pl.LY, pl.ntx, pl.tgx, pl.tgy, flip, c->tb_xmajor, c->lut_allb ? 1 : 0,         \
+                       c->lut_nrows, pl.shift, pl.omw, c->tb_stamps)
+    TB_DISPATCH(pl.T, pl.CPL, pl.guard, LAUNCH_TB);
+#undef LAUNCH_TB
+    c->cur ^= 1;
+}
+
+// n sweeps: as many T-sweep passes as fit, the rest one at a time.
+void enqueue_sweeps(deff_ctx *c, const SweepPlan &pl, int64_t n)
+{
+    if (pl.kernel == DEFF_KERNEL_MATFREE_TB) {
+        while (n >= pl.T) { enqueue_tb_pass(c, pl); n -= pl.T; ++c->last_launches; }
+    }
+    for (; n > 0; --n) { enqueue_sweep(c, pl); ++c->last_launches; }
+}
+
+extern "C" int deff_sweeps(deff_ctx *c, int64_t nsweeps, double omega, float *ms)
+try {
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    if (nsweeps < 0) return fail(DEFF_EINVAL, "negative sweep count");
+    TRY(use_device(c));
+    SweepPlan pl;
+    TRY(plan_sweeps(c, omega, &pl));
+    TRY(consolidate(c));
+    c->last_launches = 0;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    enqueue_sweeps(c, pl, nsweeps);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    if (ms) HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+// Wall fluxes of the current field (cuh:1256-1257) for every stacked row, brought to the
+// pinned host buffer: mf_host[0..rows) left wall, mf_host[rows..2*rows) right wall.
+int flux_rows(deff_ctx *c)
+{
+    if (!c->have_walls)
+        return fail(DEFF_ESTATE, "wall diffusivities unknown: pass D to deff_set_system() or assemble on the device");
+    hipLaunchKernelGGL(k_wall_flux, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, c->x[c->cur], c->Dl,
+                       c->Dr, c->nx, c->rows, c->dx, c->CL, c->CR, c->mf);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->mf_host, c->mf, sizeof(double) * 2 * c->rows, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DEFF_OK;
+}
+
+// Deff of image k from its rows of mf_host, summed in row order like the reference (cuh:1258-1263).
+static double deff_of_image(const deff_ctx *c, int k)
+{
+    const double *L = c->mf_host + (size_t)k * c->ny, *R = c->mf_host + c->rows + (size_t)k * c->ny;
+    double Q1 = 0, Q2 = 0;
+    for (int j = 0; j < c->ny; ++j) {
+        Q1 += L[j];
+        Q2 += R[j];
+    }
+    const double qAvg = (Q1 + Q2) / (2.0 * c->ny);
+    return qAvg / ((c->CR - c->CL));
+}
+
+static void copy_fluxes(const deff_ctx *c, double *MFL, double *MFR)
+{
+    if (MFL) memcpy(MFL, c->mf_host, sizeof(double) * c->rows);
+    if (MFR) memcpy(MFR, c->mf_host + c->rows, sizeof(double) * c->rows);
+}
+
+// deff_raw: nimg values (one per stacked image); MFL/MFR: rows values each, may be NULL.
+extern "C" int deff_flux(deff_ctx *c, double *deff_raw, double *MFL, double *MFR)
+try {
+    if (!c || !deff_raw) return fail(DEFF_EINVAL, "NULL argument");
+    if (!c->have_field) return fail(DEFF_ESTATE, "no field");
+    TRY(use_device(c));
+    TRY(consolidate(c));
+    TRY(flux_rows(c));
+    for (int k = 0; k < c->nimg; ++k) deff_raw[k] = deff_of_image(c, k);
+    copy_fluxes(c, MFL, MFR);
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+// JacobiGPU's loop, cuh:1232-1290, with the sweeps between two checks enqueued without host
+// round trips.  `iter` counts completed sweeps; the sweep with 0-based index k is followed by a
+// check iff k % check_every == 0 (cuh:1243).  All images of a batch start together, so their
+// checks coincide; each image carries its own deffOld / change and drops out (is frozen in the
+// buffer it is in) as soon as ITS stopping rule fires -- exactly what a one-image-at-a-time run
+// of the reference's loop would do.
+extern "C" int deff_solve_batch(deff_ctx *c, double omega, double tol, int64_t max_iter, int64_t check_every,
+                                deff_result *out, double *MFL, double *MFR)
+try {
+    if (!c || !out) return fail(DEFF_EINVAL, "NULL argument");
+    if (check_every < 1) return fail(DEFF_EINVAL, "check_every must be >= 1");
+    TRY(use_device(c));
+    SweepPlan pl;
+    TRY(plan_sweeps(c, omega, &pl));
+    if (!c->have_walls) return fail(DEFF_ESTATE, "wall diffusivities unknown (needed for Deff)");
+    TRY(consolidate(c));                                             // x is in/out: warm start from x[cur]
+    reset_batch_state(c);                                            // every image iterates again
+
+    const int B = c->nimg;
+    std::vector<double> deffNew(B, 1.0), deffOld(B, 5.0), change(B, 100.0), conv(B, 0.0);   // cuh:1171-1173
+    std::vector<int64_t> iters(B, 0), checks(B, 0);
+    int n_active = (max_iter > 0 && tol < 100.0) ? B : 0;           // cuh:1232 with change = 100
+    if (n_active == 0) c->active_h.assign(B, 0);
+    int64_t iter = 0;
+    c->last_launches = 0;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    while (iter < max_iter && n_active > 0) {                        // cuh:1232
+        const int64_t next_check = ((iter + check_every - 1) / check_every) * check_every;
+        const bool do_check = next_check < max_iter;
+        const int64_t batch = do_check ? next_check - iter + 1 : max_iter - iter;
+        enqueue_sweeps(c, pl, batch);
+        HIP_TRY(hipGetLastError());
+        iter += batch;
+        for (int k = 0; k < B; ++k)
+            if (c->active_h[k]) { iters[k] = iter; c->buf_of[k] = (uint8_t)c->cur; }
+        if (do_check) {
+            TRY(flux_rows(c));
+            bool froze = false;
+            for (int k = 0; k < B; ++k) {
+                if (!c->active_h[k]) continue;
+                deffNew[k] = deff_of_image(c, k);
+                change[k] = (deffOld[k] - deffNew[k]) / (deffOld[k]);           // cuh:1265
+                deffOld[k] = deffNew[k];
+                conv[k] = change[k];                                             // cuh:1275
+                ++checks[k];
+                if (B == 1 && c->progress) c->progress(next_check, deffNew[k], change[k], c->progress_user);
+                if (!(tol < fabs(change[k]))) { c->active_h[k] = 0; --n_active; froze = true; }
+            }
+            if (B == 1) copy_fluxes(c, MFL, MFR);
+            else {
+                // keep, per image, the fluxes of ITS last check
+                for (int k = 0; k < B; ++k)
+                    if (checks[k] && iters[k] == iter) {
+                        if (MFL) memcpy(MFL + (size_t)k * c->ny, c->mf_host + (size_t)k * c->ny, sizeof(double) * c->ny);
+                        if (MFR) memcpy(MFR + (size_t)k * c->ny, c->mf_host + c->rows + (size_t)k * c->ny,
+                                        sizeof(double) * c->ny);
+                    }
+            }
+            if (froze && n_active > 0) {
+                TRY(dev_alloc(&c->active, (size_t)B));
+                HIP_TRY(hipMemcpyAsync(c->active, c->active_h.data(), (size_t)B, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                c->masked = true;
+            }
+        }
+    }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    for (int k = 0; k < B; ++k) {
+        out[k].iters = iters[k];
+        out[k].checks = checks[k];
+        out[k].deff_raw = deffNew[k];                                // cuh:1309: value at the last check
+        out[k].conv = conv[k];
+        out[k].loop_ms = ms;                                         // the batch shares one loop
+    }
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+// ---- streaming batch ---------------------------------------------------------------------
+//
+// Dataset generation with images that converge after very different numbers of sweeps: a plain
+// batch drains (its slots empty one by one, measured 376 of ~1000 G cells*iter/s end to end on 512
+// images of 128^2).  Here a slot whose image has finished is REFILLED with the next image.  To keep
+// every image on the reference's schedule -- checks after its own sweeps 1, C+1, 2C+1, ... -- new
+// images enter exactly one sweep before a check of the running ones: that sweep is their sweep 1,
+// so all slots share the check points for ever.  Per image the arithmetic and the stopping rule are
+// those of a one-image run (cuh:1232-1290).
+
+// put image `slot`'s pixels / codes / wall data / linear guess in place (2-phase native system)
+static int stream_load_slot(deff_ctx *c, int slot, const uint8_t *pix_host)
+{
+    const size_t npix = (size_t)c->W * c->H;
+    uint8_t *dpix = c->pix + (size_t)slot * npix;
+    uint16_t *dcode = c->code + (size_t)slot * c->n_img;
+    HIP_TRY(hipMemcpyAsync(dpix, pix_host, npix, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));        // pix_host is the caller's scratch
+    hipLaunchKernelGGL(k_phase_codes, dim3(grid_for(c->n_img)), dim3(256), 0, c->stream, dpix, c->W, c->ampX, c->ampY,
+                       c->nx, c->ny, c->ny, 0, c->ny, dcode);
+    hipLaunchKernelGGL(k_wall_D_2phase, dim3((c->ny + 255) / 256), dim3(256), 0, c->stream, dpix, c->W, c->ampX, c->ampY,
+                       c->nx, c->ny, c->ny, c->Df, c->Ds, c->Dl + (size_t)slot * c->ny, c->Dr + (size_t)slot * c->ny);
+    hipLaunchKernelGGL(k_init_linear, dim3(grid_for(c->n_img)), dim3(256), 0, c->stream,
+                       c->x[c->cur] + (size_t)slot * c->n_img, c->nx, c->ny, c->CL, c->CR);
+    HIP_TRY(hipGetLastError());
+    c->buf_of[slot] = (uint8_t)c->cur;
+    return DEFF_OK;
+}
+
+static int stream_push_mask(deff_ctx *c, int n_active)
+{
+    bool all = true;
+    for (int k = 0; k < c->nimg; ++k) all = all && c->active_h[k];
+    c->masked = !all && n_active > 0;
+    if (c->masked) {
+        TRY(dev_alloc(&c->active, (size_t)c->nimg));
+        HIP_TRY(hipMemcpyAsync(c->active, c->active_h.data(), (size_t)c->nimg, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return DEFF_OK;
+}
+
+extern "C" int deff_get_slot_field(deff_ctx *c, int slot, double *x)
+try {
+    if (!c || !x || slot < 0 || slot >= c->nimg) return fail(DEFF_EINVAL, "bad slot");
+    TRY(use_device(c));
+    HIP_TRY(hipMemcpyAsync(x, c->x[(c->masked || c->in_stream) ? c->buf_of[slot] : c->cur] + (size_t)slot * c->n_img,
+                           sizeof(double) * c->n_img, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+extern "C" int deff_solve_stream(deff_ctx *c, int W, int H, int ampX, int ampY, double Ds, double Df, double CL,
+                                 double CR, double omega, double tol, int64_t max_iter, int64_t check_every,
+                                 deff_next_image_fn next, deff_image_done_fn done, void *user)
+try {
+    if (!c || !next || !done) return fail(DEFF_EINVAL, "NULL argument");
+    if (check_every < 1) return fail(DEFF_EINVAL, "check_every must be >= 1");
+    if (c->slab) return fail(DEFF_EINVAL, "not for slab contexts");
+    TRY(use_device(c));
+    TRY(image_shape(c, W, H, ampX, ampY));
+    TRY(ensure_walls(c));
+    TRY(dev_alloc(&c->code, c->n));
+    const int B = c->nimg;
+    c->CL = CL; c->CR = CR; c->Ds = Ds; c->Df = Df;
+    build_lut_rows(c, Ds, Df, CL, CR);
+    c->have_image = true; c->have_walls = true; c->have_matfree = true; c->have_explicit = false;
+    c->dict_tried = false; c->have_field = true;
+    HIP_TRY(hipMemsetAsync(c->code, 0, sizeof(uint16_t) * c->n, c->stream));      // empty slots: zero rows
+    HIP_TRY(hipMemsetAsync(c->x[0], 0, sizeof(double) * c->n, c->stream));
+    HIP_TRY(hipMemsetAsync(c->x[1], 0, sizeof(double) * c->n, c->stream));
+    reset_batch_state(c);
+
+    struct Slot { bool live = false; int64_t id = -1, iters = 0, checks = 0; double deffNew = 1, deffOld = 5, change = 100, conv = 0; };
+    std::vector<Slot> S(B);
+    std::vector<uint8_t> pixbuf((size_t)W * H);
+    bool more = true;
+    int n_active = 0;
+    auto refill = [&]() -> int {                       // fill every free slot while images remain
+        for (int k = 0; k < B && more; ++k) {
+            if (S[k].live) continue;
+            int64_t id = -1;
+            const int got = next(user, k, pixbuf.data(), &id);
+            if (got < 0) return fail(DEFF_EINVAL, "image source reported an error");
+            if (got == 0) { more = false; break; }
+            TRY(stream_load_slot(c, k, pixbuf.data()));
+            S[k] = Slot();
+            S[k].live = true; S[k].id = id;
+            c->active_h[k] = 1;
+            ++n_active;
+        }
+        return DEFF_OK;
+    };
+    auto retire = [&](int k, float ms) {
+        deff_result r;
+        r.iters = S[k].iters; r.checks = S[k].checks; r.deff_raw = S[k].deffNew; r.conv = S[k].conv; r.loop_ms = ms;
+        c->active_h[k] = 0;
+        --n_active;
+        done(user, S[k].id, k, &r);                    // the slot's field is still readable (deff_get_slot_field)
+        S[k].live = false;
+    };
+    auto advance = [&](SweepPlan &pl, int64_t nsw) -> int {
+        if (nsw <= 0) return DEFF_OK;
+        enqueue_sweeps(c, pl, nsw);
+        HIP_TRY(hipGetLastError());
+        for (int k = 0; k < B; ++k)
+            if (S[k].live) { S[k].iters += nsw; c->buf_of[k] = (uint8_t)c->cur; }
+        return DEFF_OK;
+    };
+
+    for (int k = 0; k < B; ++k) c->active_h[k] = 0;
+    c->in_stream = true;
+    struct Leave { deff_ctx *c; ~Leave() { c->in_stream = false; } } leave{c};
+    TRY(refill());
+    SweepPlan pl;
+    TRY(plan_sweeps(c, omega, &pl));
+    c->last_launches = 0;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (!(max_iter > 0 && tol < 100.0)) {               // cuh:1232 with change = 100: no sweep at all
+        for (;;) {
+            for (int k = 0; k < B; ++k) if (S[k].live) retire(k, 0.f);
+            if (!more) break;
+            TRY(refill());
+            if (n_active == 0) break;
+        }
+    }
+    // phase of max_iter inside a check interval: live images sit at iters = j*C + 1 after a check
+    while (n_active > 0) {
+        TRY(stream_push_mask(c, n_active));
+        // one sweep (the first of the newly loaded images, sweep j*C + 1 of the others), then the check
+        TRY(advance(pl, 1));
+        TRY(flux_rows(c));
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        HIP_TRY(hipEventSynchronize(c->ev1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        for (int k = 0; k < B; ++k) {
+            if (!S[k].live) continue;
+            Slot &s = S[k];
+            s.deffNew = deff_of_image(c, k);
+            s.change = (s.deffOld - s.deffNew) / (s.deffOld);                     // cuh:1265
+            s.deffOld = s.deffNew;
+            s.conv = s.change;
+            ++s.checks;
+            if (!(tol < fabs(s.change)) || s.iters >= max_iter) retire(k, ms);
+        }
+        if (n_active == 0 && !more) break;
+        // up to the next check: C - 1 sweeps, split where images run into max_iter (they all carry
+        // iters = j*C + 1 with their own j, so each reaches max_iter the same distance after a check)
+        int64_t left = check_every - 1;
+        while (left > 0 && n_active > 0) {
+            int64_t seg = left;
+            for (int k = 0; k < B; ++k)
+                if (S[k].live && max_iter - S[k].iters < seg) seg = max_iter - S[k].iters;
+            if (seg > 0) {
+                TRY(stream_push_mask(c, n_active));
+                TRY(advance(pl, seg));
+                left -= seg;
+            }
+            bool hit = false;
+            for (int k = 0; k < B; ++k)
+                if (S[k].live && S[k].iters >= max_iter) { hit = true; }
+            if (hit) {
+                HIP_TRY(hipEventRecord(c->ev1, c->stream));
+                HIP_TRY(hipEventSynchronize(c->ev1));
+                float ms2 = 0;
+                HIP_TRY(hipEventElapsedTime(&ms2, c->ev0, c->ev1));
+                for (int k = 0; k < B; ++k)
+                    if (S[k].live && S[k].iters >= max_iter) retire(k, ms2);   // MAX_ITER reached between checks, cuh:1232
+            }
+        }
+        TRY(refill());                                 // newcomers start with the sweep that precedes the next check
+    }
+    c->masked = false;
+    reset_batch_state(c);
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+extern "C" int deff_solve(deff_ctx *c, double omega, double tol, int64_t max_iter, int64_t check_every,
+                          deff_result *out, double *MFL, double *MFR)
+try {
+    if (c && c->nimg != 1) return fail(DEFF_EINVAL, "context holds %d images: use deff_solve_batch()", c->nimg);
+    return deff_solve_batch(c, omega, tol, max_iter, check_every, out, MFL, MFR);
+}
+DEFF_API_CATCH
+
+// Diagnostics: time-stamp every wave tile of ONE temporally blocked pass (100 MHz wall clock ticks).
+// out[2*k], out[2*k+1] = start, end of wave tile k; *ntiles = number of tiles (call with out = NULL
+// to size the buffer).  Advances the field by one pass.
+extern "C" int deff_debug_tb_stamps(deff_ctx *c, double omega, unsigned long long *out, int *ntiles)
+try {
+    if (!c || !ntiles) return fail(DEFF_EINVAL, "NULL argument");
+    TRY(use_device(c));
+    SweepPlan pl;
+    TRY(plan_sweeps(c, omega, &pl));
+    if (pl.kernel != DEFF_KERNEL_MATFREE_TB) return fail(DEFF_ESTATE, "not on the temporally blocked kernel");
+    const int n = pl.ntx * pl.tgy;
+    *ntiles = n;
+    if (!out) return DEFF_OK;
+    HIP_TRY(hipMalloc((void **)&c->tb_stamps, sizeof(unsigned long long) * 2 * n));
+    HIP_TRY(hipMemsetAsync(c->tb_stamps, 0, sizeof(unsigned long long) * 2 * n, c->stream));
+    enqueue_tb_pass(c, pl);
+    hipError_t e = hipMemcpyAsync(out, c->tb_stamps, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(c->tb_stamps);
+    c->tb_stamps = nullptr;
+    if (e != hipSuccess) return fail(DEFF_EHIP, "stamp readback failed: %s", hipGetErrorString(e));
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+extern "C" int deff_set_progress(deff_ctx *c, deff_progress_fn fn, void *user)
+try {
+    if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
+    c->progress = fn;
+    c->progress_user = user;
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+extern "C" int deff_last_launches(const deff_ctx *c, int64_t *launches, int *sweeps_per_pass)
+try {
+    if (!c || !launches) return fail(DEFF_EINVAL, "NULL argument");
+    *launches = c->last_launches;
+    if (sweeps_per_pass) {
+        int k = 0;
+        *sweeps_per_pass = 1;
+        if (resolve_kernel(c, &k) == DEFF_OK && k == DEFF_KERNEL_MATFREE_TB) {
+            int T = c->tb_T ? c->tb_T : default_tb_T(c);
+            *sweeps_per_pass = T >= 8 ? 8 : T >= 6 ? 6 : T >= 4 ? 4 : 2;
+        }
+    }
+    return DEFF_OK;
+}
+DEFF_API_CATCH

@@ -1,0 +1,224 @@
+// ctx.hpp -- what the translation units of libdeff_amd.so share: the solver context, the error
+// helpers and the internal entry points that cross files.
+//   api_core.hip   library, context lifecycle, image, assembly (native / from D / imported), field
+//   api_solve.hip  row dictionary, launch plans, sweeps, wall fluxes, the solve loops (one image,
+//                  batch, streaming batch)
+//   api_slab.hip   one image over several GPUs: row slabs (peer copies in one process, RCCL or a
+//                  caller-supplied transport with one process per GPU)
+// The library is built with -fvisibility=hidden; only the C ABI of include/deff_amd.h is exported.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#pragma GCC visibility push(default)
+#include "../../include/deff_amd.h"
+#pragma GCC visibility pop
+#include "fvm_row.hpp"
+#include "kernels_setup.hpp"
+#include "lut_layout.hpp"
+
+using namespace deff;
+
+// ------------------------------------------------------------- errors -----
+
+extern thread_local char g_err[512];                 // message of this thread's last failure (api_core.hip)
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail(e_ == hipErrorOutOfMemory ? DEFF_ENOMEM : DEFF_EHIP,             \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                       \
+    } while (0)
+
+#define TRY(expr)                  \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != DEFF_OK) return rc_; \
+    } while (0)
+
+// ------------------------------------------------------------ context -----
+
+struct deff_ctx {
+    int device = 0;
+    int nx = 0, ny = 0;             // mesh of ONE image
+    int nimg = 1;                   // images stacked in this context (batch), see kernels_setup.hpp
+    int rows = 0;                   // nimg * ny
+    size_t n_img = 0;               // cells per image
+    size_t n = 0;                   // cells in the stack
+    double dx = 0, dy = 0;
+    // Row slab of a taller image (multi-GPU split of one image): the arrays hold
+    // `halo` rows above and below the `own_h` rows this context updates; array row li is mesh row
+    // li - dom_lo of a mesh_ny-row mesh.  Plain contexts: dom_lo = 0, mesh_ny = own_h = ny, halo = 0.
+    bool slab = false;
+    int dom_lo = 0, mesh_ny = 0, own_lo = 0, own_h = 0, halo = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // image (pixels as decoded, W x H, before mesh amplification)
+    uint8_t *pix = nullptr;
+    int W = 0, H = 0, ampX = 1, ampY = 1;
+    bool have_image = false;
+
+    // explicit SoA system
+    double *a0 = nullptr, *c0 = nullptr, *aW = nullptr, *aE = nullptr, *aS = nullptr, *aN = nullptr,
+           *b = nullptr;
+    bool have_explicit = false;
+    double c0_omega = NAN;          // omega the c0 plane was built for
+
+    // matrix-free system: one 16-bit code per cell + the dictionary of distinct rows (lut_layout.hpp)
+    uint16_t *code = nullptr;
+    double *lut = nullptr;          // device tables [LUT_PLANES][LUT_PLANE_STRIDE]
+    std::vector<double> lut_rows;   // host: rows [nrows][6] = A0, aW, aE, aS, aN, b (row 0 = zeros)
+    int lut_nrows = 0;
+    bool lut_allb = false;          // some row away from the walls has b != 0 (harvested dictionaries only)
+    bool lut_guard = false;         // some c0 = w/A0 is not finite: the reference's non-zero link test matters
+    bool have_matfree = false;
+    bool dict_tried = false;        // a dictionary was already looked for in the current explicit system
+    int dict_enabled = 1;
+    double lut_omega = NAN;
+    double Ds = 0, Df = 0;          // phase diffusivities of the native 2-phase system
+
+    // wall data for the flux evaluation
+    double *Dl = nullptr, *Dr = nullptr;
+    double CL = 0, CR = 0;
+    bool have_walls = false;
+    double *mf = nullptr;           // device: 2*ny fluxes
+    double *mf_host = nullptr;      // pinned
+
+    // field, ping-pong
+    double *x[2] = {nullptr, nullptr};
+    int cur = 0;
+    bool have_field = false;
+    // batch bookkeeping: images still iterating (device mask is only bound while some are
+    // frozen) and, per image, the ping-pong buffer that holds its newest field
+    uint8_t *active = nullptr;
+    std::vector<uint8_t> active_h, buf_of;
+    bool masked = false;
+    bool in_stream = false;         // inside deff_solve_stream: buf_of[] is current for every slot
+
+    // scratch for chunked uploads (AoS import, D upload)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+
+    deff_progress_fn progress = nullptr;
+    void *progress_user = nullptr;
+
+    int kernel = DEFF_KERNEL_AUTO;
+    int rows_explicit = 0, rows_matfree = 0;     // rows per register tile, 0 = default
+    int wg_matfree = 0;                          // persistent workgroups of the matrix-free kernel, 0 = default
+    int nt_explicit = 1;                         // non-temporal coefficient loads in the explicit kernels
+    int serpentine = 1;                          // alternate the tile walk direction from sweep to sweep
+    int tb_T = 0, tb_LY = 0, tb_wg = 0;          // temporal blocking: sweeps per pass, rows per chunk, workgroups
+    unsigned long long *tb_stamps = nullptr;     // diagnostics: per wave-tile start/end clocks (deff_debug_tb_stamps)
+    int tb_wall_halo = 2;                        // strip placement: 1 = halo also outside the walls, 0 = not, 2 = whichever needs fewer strips
+    int plan_T = 0, plan_LY = 0, plan_ntx = 0, plan_cpi = 0, plan_blocks = 0;   // last temporally blocked plan
+    int tb_xmajor = 1;                           // wave-tile numbering of the temporally blocked kernel
+    int64_t last_launches = 0;                   // sweep-kernel launches of the last deff_sweeps()/deff_solve()
+};
+
+static inline int use_device(const deff_ctx *c)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    return DEFF_OK;
+}
+
+template <typename T>
+static inline int dev_alloc(T **p, size_t count)
+{
+    if (*p) return DEFF_OK;
+    HIP_TRY(hipMalloc((void **)p, count * sizeof(T)));
+    return DEFF_OK;
+}
+
+static inline int ensure_scratch(deff_ctx *c, size_t bytes)
+{
+    if (c->scratch_bytes >= bytes) return DEFF_OK;
+    if (c->scratch) { HIP_TRY(hipFree(c->scratch)); c->scratch = nullptr; c->scratch_bytes = 0; }
+    HIP_TRY(hipMalloc(&c->scratch, bytes));
+    c->scratch_bytes = bytes;
+    return DEFF_OK;
+}
+
+static inline int ensure_explicit(deff_ctx *c)
+{
+    TRY(dev_alloc(&c->a0, c->n)); TRY(dev_alloc(&c->c0, c->n));
+    TRY(dev_alloc(&c->aW, c->n)); TRY(dev_alloc(&c->aE, c->n));
+    TRY(dev_alloc(&c->aS, c->n)); TRY(dev_alloc(&c->aN, c->n));
+    TRY(dev_alloc(&c->b, c->n));
+    return DEFF_OK;
+}
+
+static inline int ensure_walls(deff_ctx *c)
+{
+    TRY(dev_alloc(&c->Dl, (size_t)c->rows));
+    TRY(dev_alloc(&c->Dr, (size_t)c->rows));
+    TRY(dev_alloc(&c->mf, (size_t)2 * c->rows));
+    if (!c->mf_host) HIP_TRY(hipHostMalloc((void **)&c->mf_host, sizeof(double) * 2 * c->rows));
+    return DEFF_OK;
+}
+
+static inline int grid_for(size_t n, int cap = 16384)
+{
+    size_t g = (n + 255) / 256;
+    return (int)(g < (size_t)cap ? (g ? g : 1) : (size_t)cap);
+}
+
+static inline CoefSoA soa_of(deff_ctx *c) { return CoefSoA{c->a0, c->aW, c->aE, c->aS, c->aN, c->b}; }
+
+// No C++ exception may unwind through the C ABI: every `extern "C" int` entry point is a
+// function-try-block ending in DEFF_API_CATCH, which turns std::bad_alloc (host vectors sized by the
+// caller's image) and anything else into an error code + message.
+static inline int api_exception() noexcept
+{
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        return fail(DEFF_ENOMEM, "host allocation failed");
+    } catch (const std::exception &e) {
+        return fail(DEFF_EINVAL, "internal error: %s", e.what());
+    } catch (...) {
+        return fail(DEFF_EINVAL, "internal error: unknown exception");
+    }
+}
+#define DEFF_API_CATCH catch (...) { return api_exception(); }
+
+// ------------------------------------------------- shared internals -------
+
+struct SweepPlan {
+    int kernel = 0;
+    double omw = 0;
+    int rows = 0, cpi = 0, gx = 0, gy = 0, blocks = 0;   // single-sweep kernels (cpi: row tiles per image)
+    // temporally blocked kernel
+    int T = 0, CPL = 2, LY = 0, tcpi = 0, ntx = 0, tgx = 0, tgy = 0, tblocks = 0;
+    int shift = 0;                                        // column shift of the strips (0: no halo outside the walls)
+    int T_override = 0;                                   // slab mode plans a T = 1 pass for remainders
+    bool guard = false;
+};
+
+// api_core.hip
+void reset_batch_state(deff_ctx *c);
+int resolve_kernel(const deff_ctx *c, int *k);
+int image_shape(deff_ctx *c, int W, int H, int ampX, int ampY);
+void build_lut_rows(deff_ctx *c, double Ds, double Df, double CL, double CR);
+int upload_lut(deff_ctx *c, double omega);
+int consolidate(deff_ctx *c);
+int explicit_from_image(deff_ctx *c);
+// api_solve.hip
+int default_tb_T(const deff_ctx *c);
+int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl);
+void enqueue_sweep(deff_ctx *c, const SweepPlan &pl);
+void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl);
+void enqueue_sweeps(deff_ctx *c, const SweepPlan &pl, int64_t n);
+int flux_rows(deff_ctx *c);

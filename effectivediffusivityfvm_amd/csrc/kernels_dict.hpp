@@ -65,7 +65,7 @@ __device__ __forceinline__ unsigned dict_slot(DictTable t, unsigned long long h,
     return DICT_SLOTS;
 }
 
-__global__ void k_dict_insert(CoefSoA c, size_t n, DictTable t)
+static __global__ void k_dict_insert(CoefSoA c, size_t n, DictTable t)
 {
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
         const unsigned s = dict_slot(t, row_hash(c, p), true);
@@ -76,7 +76,7 @@ __global__ void k_dict_insert(CoefSoA c, size_t n, DictTable t)
 }
 
 // slot2code[s] = code (row index x 8) of slot s, 0xFFFF when the slot got no row (too many rows)
-__global__ void k_dict_encode(CoefSoA c, size_t n, int nx, DictTable t, const uint16_t *__restrict__ slot2code,
+static __global__ void k_dict_encode(CoefSoA c, size_t n, int nx, DictTable t, const uint16_t *__restrict__ slot2code,
                               uint16_t *__restrict__ code)
 {
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
@@ -97,7 +97,7 @@ __global__ void k_dict_encode(CoefSoA c, size_t n, int nx, DictTable t, const ui
 }
 
 // rows[k*6 + plane] = plane[cell[k]] for the representatives
-__global__ void k_dict_gather(CoefSoA c, const unsigned long long *__restrict__ cell, int nrows, double *__restrict__ rows)
+static __global__ void k_dict_gather(CoefSoA c, const unsigned long long *__restrict__ cell, int nrows, double *__restrict__ rows)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nrows) return;

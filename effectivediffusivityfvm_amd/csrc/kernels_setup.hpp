@@ -27,7 +27,7 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
     return z ^ (z >> 31);
 }
 
-__global__ void k_synth_mask(uint8_t *__restrict__ pix, int nx, int ny, uint64_t seed, uint64_t img)
+static __global__ void k_synth_mask(uint8_t *__restrict__ pix, int nx, int ny, uint64_t seed, uint64_t img)
 {
     const size_t n = (size_t)nx * ny;
     const uint64_t base = seed * 0x100000001B3ull + img * (uint64_t)n;
@@ -38,7 +38,7 @@ __global__ void k_synth_mask(uint8_t *__restrict__ pix, int nx, int ny, uint64_t
 
 // Same generator for `count` consecutive cells starting at global cell index `first` of the
 // image sequence (row slabs generate only their own window of the image).
-__global__ void k_synth_mask_at(uint8_t *__restrict__ pix, size_t count, uint64_t seed, uint64_t first)
+static __global__ void k_synth_mask_at(uint8_t *__restrict__ pix, size_t count, uint64_t seed, uint64_t first)
 {
     const uint64_t base = seed * 0x100000001B3ull + first;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < count;
@@ -57,7 +57,7 @@ __device__ __forceinline__ uint8_t cell_pixel(const uint8_t *pix, int W, int amp
 }
 
 // 2-phase D fill, cuh:1988-2000: pixel < 150 -> fluid.
-__global__ void k_fill_D_2phase(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
+static __global__ void k_fill_D_2phase(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
                                 int nx, int ny, int rows, double DCF, double DCS, double *__restrict__ D)
 {
     const size_t n = (size_t)nx * rows;
@@ -69,7 +69,7 @@ __global__ void k_fill_D_2phase(const uint8_t *__restrict__ pix, int W, int ampX
 }
 
 // 3-phase D fill, cuh:1518-1529: pixel > 200 -> solid, < 50 -> gas, otherwise fluid.
-__global__ void k_fill_D_3phase(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
+static __global__ void k_fill_D_3phase(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
                                 int nx, int ny, int rows, double DCF, double DCS, double DCG,
                                 double *__restrict__ D)
 {
@@ -84,7 +84,7 @@ __global__ void k_fill_D_3phase(const uint8_t *__restrict__ pix, int W, int ampX
 
 // Diffusivity of the first and last cell of every row, for the wall fluxes
 // (cuh:1256-1257 read D[j*nx] and D[(j+1)*nx-1]).
-__global__ void k_wall_D_2phase(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
+static __global__ void k_wall_D_2phase(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
                                 int nx, int ny, int rows, double DCF, double DCS,
                                 double *__restrict__ Dl, double *__restrict__ Dr)
 {
@@ -94,7 +94,7 @@ __global__ void k_wall_D_2phase(const uint8_t *__restrict__ pix, int W, int ampX
     Dr[i] = (cell_pixel(pix, W, ampX, ampY, ny, i, nx - 1) < 150) ? DCF : DCS;
 }
 
-__global__ void k_wall_D_from_D(const double *__restrict__ D, int nx, int rows,
+static __global__ void k_wall_D_from_D(const double *__restrict__ D, int nx, int rows,
                                 double *__restrict__ Dl, double *__restrict__ Dr)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -111,7 +111,7 @@ __global__ void k_wall_D_from_D(const double *__restrict__ D, int nx, int rows,
 // cell; their bits do not matter because the position class already removes those links.
 // dom_lo / mesh_ny: array row li of an image is mesh row li - dom_lo of a mesh_ny-row mesh
 // (dom_lo = 0, mesh_ny = ny except for a row slab, whose array is a window with halo rows).
-__global__ void k_phase_codes(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
+static __global__ void k_phase_codes(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
                               int nx, int ny, int rows, int dom_lo, int mesh_ny,
                               uint16_t *__restrict__ code)
 {
@@ -144,7 +144,7 @@ struct CoefSoA {
 // General assembly from a per-cell D array (DiscretizeMatrix2D cuh:815-902;
 // with Grid != nullptr, DiscretizeMatrix2D_ImpSolid cuh:715-812: Grid 1 or 2
 // gets the identity row, cuh:750-752).
-__global__ void k_assemble_from_D(const double *__restrict__ D, const unsigned int *__restrict__ Grid,
+static __global__ void k_assemble_from_D(const double *__restrict__ D, const unsigned int *__restrict__ Grid,
                                   int nx, int ny, int rows, double dx, double dy, double CL, double CR,
                                   CoefSoA c)
 {
@@ -169,7 +169,7 @@ __global__ void k_assemble_from_D(const double *__restrict__ D, const unsigned i
 }
 
 // AoS [cells][5] chunk -> SoA planes (import of a host-assembled matrix).
-__global__ void k_import_aos(const double *__restrict__ A, size_t first, size_t count, CoefSoA c)
+static __global__ void k_import_aos(const double *__restrict__ A, size_t first, size_t count, CoefSoA c)
 {
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < count;
          q += (size_t)gridDim.x * blockDim.x) {
@@ -179,7 +179,7 @@ __global__ void k_import_aos(const double *__restrict__ A, size_t first, size_t 
     }
 }
 
-__global__ void k_export_aos(double *__restrict__ A, size_t first, size_t count, CoefSoA c)
+static __global__ void k_export_aos(double *__restrict__ A, size_t first, size_t count, CoefSoA c)
 {
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < count;
          q += (size_t)gridDim.x * blockDim.x) {
@@ -192,7 +192,7 @@ __global__ void k_export_aos(double *__restrict__ A, size_t first, size_t count,
 // c0 = w / A0: the reference evaluates w/A[p*5+0] first and multiplies the
 // result by (b - sigma) (cuh:89, C precedence), so hoisting the division out
 // of the sweep keeps every bit.
-__global__ void k_make_c0(const double *__restrict__ a0, double w, double *__restrict__ c0, size_t n)
+static __global__ void k_make_c0(const double *__restrict__ a0, double w, double *__restrict__ c0, size_t n)
 {
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
          p += (size_t)gridDim.x * blockDim.x)
@@ -202,7 +202,7 @@ __global__ void k_make_c0(const double *__restrict__ a0, double w, double *__res
 // ---------------------------------------------------------------- field ---
 
 // Linear ramp, cuh:1955-1959: (double)j/nx*(CR-CL)+CL.
-__global__ void k_init_linear(double *__restrict__ x, int nx, int rows, double CL, double CR)
+static __global__ void k_init_linear(double *__restrict__ x, int nx, int rows, double CL, double CR)
 {
     const size_t n = (size_t)nx * rows;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
@@ -215,7 +215,7 @@ __global__ void k_init_linear(double *__restrict__ x, int nx, int rows, double C
 // Wall fluxes of every row, cuh:1256-1257.  The host adds them up in row order
 // (cuh:1258-1259) so Deff has the reference's summation order; the transfer is
 // 16*ny bytes per check instead of the reference's whole field (cuh:1245).
-__global__ void k_wall_flux(const double *__restrict__ x, const double *__restrict__ Dl,
+static __global__ void k_wall_flux(const double *__restrict__ x, const double *__restrict__ Dl,
                             const double *__restrict__ Dr, int nx, int rows, double dx,
                             double CL, double CR, double *__restrict__ mf)
 {
