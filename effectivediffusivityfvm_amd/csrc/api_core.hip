@@ -206,6 +206,7 @@ try {
     else if (!strcmp(key, "tb_LY")) c->tb_LY = value;
     else if (!strcmp(key, "dict")) c->dict_enabled = value ? 1 : 0;
     else if (!strcmp(key, "tb_xmajor")) c->tb_xmajor = value ? 1 : 0;
+    else if (!strcmp(key, "fma")) c->fma = value ? 1 : 0;
     else if (!strcmp(key, "tb_wall_halo")) c->tb_wall_halo = value > 2 ? 2 : value;
     else if (!strcmp(key, "tb_wg")) c->tb_wg = (value + 7) / 8 * 8;
     else return fail(DEFF_EINVAL, "unknown tuning key '%s'", key);
@@ -550,7 +551,7 @@ try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     TRY(use_device(c));
     hipLaunchKernelGGL(k_init_linear, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->x[c->cur], c->nx,
-                       c->rows, CL, CR);
+                       c->rows, CL, CR, c->fma);
     HIP_TRY(hipGetLastError());
     c->have_field = true;
     reset_batch_state(c);

@@ -9,34 +9,38 @@
 // ----------------------------------------------------------- sweeps -------
 
 // Workgroups of the temporally blocked kernel that are resident at once on this device.
-template <int T, int CPL, bool G>
+template <int T, bool F, bool G>
 static int tb_occ(int *per_cu)
 {
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_sweep_matfree_tb<T, CPL, G>, 256, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_sweep_matfree_tb<T, F, G>, 256, 0));
     return DEFF_OK;
 }
 
 // Only 2 cells per lane are instantiated: 4 per lane (twice the work per wave, 244 VGPRs,
 // 2 waves per SIMD) measured 20 % slower at 4096^2 -- the kernel needs the wave-level
 // parallelism more than it needs the smaller strip overlap.
-#define TB_DISPATCH(T_, CPL_, G_, CALL)                                                     \
+#define TB_DISPATCH_FG(TC_, F_, G_, CALL)                                                   \
+    switch (((F_) ? 2 : 0) + ((G_) ? 1 : 0)) {                                              \
+    case 1: { CALL(TC_, false, true); } break;  case 2: { CALL(TC_, true, false); } break; \
+    case 3: { CALL(TC_, true, true); } break;   default: { CALL(TC_, false, false); } break; \
+    }
+#define TB_DISPATCH(T_, F_, G_, CALL)                                                       \
     do {                                                                                    \
-        const int key_ = (T_) * 10 + ((G_) ? 1 : 0);                                        \
-        switch (key_) {                                                                     \
-        case 10: { CALL(1, 2, false); } break; case 11: { CALL(1, 2, true); } break;       \
-        case 20: { CALL(2, 2, false); } break; case 21: { CALL(2, 2, true); } break;       \
-        case 40: { CALL(4, 2, false); } break; case 41: { CALL(4, 2, true); } break;       \
-        case 60: { CALL(6, 2, false); } break; case 61: { CALL(6, 2, true); } break;       \
-        default: { CALL(8, 2, false); } break; case 81: { CALL(8, 2, true); } break;       \
+        switch (T_) {                                                                       \
+        case 1: TB_DISPATCH_FG(1, F_, G_, CALL); break;                                     \
+        case 2: TB_DISPATCH_FG(2, F_, G_, CALL); break;                                     \
+        case 4: TB_DISPATCH_FG(4, F_, G_, CALL); break;                                     \
+        case 6: TB_DISPATCH_FG(6, F_, G_, CALL); break;                                     \
+        default: TB_DISPATCH_FG(8, F_, G_, CALL); break;                                    \
         }                                                                                   \
     } while (0)
 
-static int tb_resident_blocks(const deff_ctx *c, int T, int CPL, bool guard, int *resident)
+static int tb_resident_blocks(const deff_ctx *c, int T, bool fma, bool guard, int *resident)
 {
     int per_cu = 0, cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
 #define OCC_CALL(T_, C_, G_) TRY((tb_occ<T_, C_, G_>(&per_cu)))
-    TB_DISPATCH(T, CPL, guard, OCC_CALL);
+    TB_DISPATCH(T, fma, guard, OCC_CALL);
 #undef OCC_CALL
     if (per_cu < 1) per_cu = 1;
     *resident = per_cu * cus;
@@ -142,6 +146,7 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
         (c->kernel == DEFF_KERNEL_AUTO || c->kernel == DEFF_KERNEL_MATFREE || c->kernel == DEFF_KERNEL_MATFREE_TB))
         TRY(try_dict(c));
     TRY(resolve_kernel(c, &pl->kernel));
+    pl->fma = c->fma != 0;
     pl->omw = 1.0 - omega;                              // cuh:89 evaluates (1.0 - w) in double
     if (pl->kernel == DEFF_KERNEL_MATFREE || pl->kernel == DEFF_KERNEL_MATFREE_TB) {
         TRY(upload_lut(c, omega));
@@ -171,7 +176,7 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             // count that fits matters.  (Stacks of small images: 3 072 x 128^2 as whole-image tiles
             // 1 266 G cells*iter/s against 1 107 G for the 4 x 32-row tiles a halo-blind model picks.)
             int resident = c->tb_wg;
-            if (!resident) TRY(tb_resident_blocks(c, T, pl->CPL, c->lut_guard, &resident));
+            if (!resident) TRY(tb_resident_blocks(c, T, pl->fma, c->lut_guard, &resident));
             int LY = c->tb_LY;
             if (!LY) {
                 long best_cost = -1;
@@ -230,23 +235,23 @@ void enqueue_sweep(deff_ctx *c, const SweepPlan &pl)
     const int flip = c->serpentine ? c->cur : 0;
     const uint8_t *mask = c->masked ? c->active : nullptr;
     switch (pl.kernel) {
-    case DEFF_KERNEL_SCALAR:
-        if (c->nt_explicit)
-            hipLaunchKernelGGL(k_sweep_scalar<true>, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
-                               cf, xin, xout, c->nx, c->n, c->n_img, mask, pl.omw);
-        else
-            hipLaunchKernelGGL(k_sweep_scalar<false>, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
-                               cf, xin, xout, c->nx, c->n, c->n_img, mask, pl.omw);
+    case DEFF_KERNEL_SCALAR: {
+#define LAUNCH_SCALAR(NT_, F_)                                                                              \
+    hipLaunchKernelGGL((k_sweep_scalar<NT_, F_>), dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0,       \
+                       c->stream, cf, xin, xout, c->nx, c->n, c->n_img, mask, pl.omw)
+        if (c->nt_explicit) { if (pl.fma) LAUNCH_SCALAR(true, true); else LAUNCH_SCALAR(true, false); }
+        else { if (pl.fma) LAUNCH_SCALAR(false, true); else LAUNCH_SCALAR(false, false); }
+#undef LAUNCH_SCALAR
         break;
+    }
     case DEFF_KERNEL_EXPLICIT: {
+#define LAUNCH_EXPLICIT_(R_, NT_, F_)                                                                        \
+    hipLaunchKernelGGL((k_sweep_explicit<R_, NT_, F_>), dim3(pl.blocks), dim3(256), 0, c->stream, cf, xin,   \
+                       xout, c->nx, c->ny, c->rows, pl.cpi, mask, pl.gx, pl.gy, flip, pl.omw)
 #define LAUNCH_EXPLICIT(R_)                                                                                  \
     do {                                                                                                    \
-        if (c->nt_explicit)                                                                                 \
-            hipLaunchKernelGGL((k_sweep_explicit<R_, true>), dim3(pl.blocks), dim3(256), 0, c->stream, cf,  \
-                               xin, xout, c->nx, c->ny, c->rows, pl.cpi, mask, pl.gx, pl.gy, flip, pl.omw); \
-        else                                                                                                \
-            hipLaunchKernelGGL((k_sweep_explicit<R_, false>), dim3(pl.blocks), dim3(256), 0, c->stream, cf, \
-                               xin, xout, c->nx, c->ny, c->rows, pl.cpi, mask, pl.gx, pl.gy, flip, pl.omw); \
+        if (c->nt_explicit) { if (pl.fma) LAUNCH_EXPLICIT_(R_, true, true); else LAUNCH_EXPLICIT_(R_, true, false); } \
+        else { if (pl.fma) LAUNCH_EXPLICIT_(R_, false, true); else LAUNCH_EXPLICIT_(R_, false, false); }   \
     } while (0)
         switch (pl.rows) {
         case 1: LAUNCH_EXPLICIT(1); break;
@@ -255,12 +260,16 @@ void enqueue_sweep(deff_ctx *c, const SweepPlan &pl)
         default: LAUNCH_EXPLICIT(8); break;
         }
 #undef LAUNCH_EXPLICIT
+#undef LAUNCH_EXPLICIT_
         break;
     }
     default: {
+#define LAUNCH_MATFREE_(V_, R_, F_)                                                                          \
+    hipLaunchKernelGGL((k_sweep_matfree<V_, R_, F_>), dim3(pl.blocks), dim3(256), 0, c->stream, c->lut,      \
+                       c->code, xin, xout, c->nx, c->ny, c->rows, pl.cpi, mask, pl.gx, pl.gy, flip,          \
+                       c->lut_nrows, pl.omw)
 #define LAUNCH_MATFREE(V_, R_)                                                                               \
-    hipLaunchKernelGGL((k_sweep_matfree<V_, R_>), dim3(pl.blocks), dim3(256), 0, c->stream, c->lut, c->code, \
-                       xin, xout, c->nx, c->ny, c->rows, pl.cpi, mask, pl.gx, pl.gy, flip, c->lut_nrows, pl.omw)
+    do { if (pl.fma) LAUNCH_MATFREE_(V_, R_, true); else LAUNCH_MATFREE_(V_, R_, false); } while (0)
         if (c->nx & 1) {
             switch (pl.rows) {
             case 1: LAUNCH_MATFREE(1, 1); break;
@@ -277,6 +286,7 @@ void enqueue_sweep(deff_ctx *c, const SweepPlan &pl)
             }
         }
 #undef LAUNCH_MATFREE
+#undef LAUNCH_MATFREE_
         break;
     }
     }
@@ -295,7 +305,7 @@ void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl)
                        c->code, xin, xout, c->nx, c->mesh_ny, c->ny, c->dom_lo, c->own_lo, c->own_h, pl.tcpi, \
                        mask, pl.LY, pl.ntx, pl.tgx, pl.tgy, flip, c->tb_xmajor, c->lut_allb ? 1 : 0,         \
                        c->lut_nrows, pl.shift, pl.omw, c->tb_stamps)
-    TB_DISPATCH(pl.T, pl.CPL, pl.guard, LAUNCH_TB);
+    TB_DISPATCH(pl.T, pl.fma, pl.guard, LAUNCH_TB);
 #undef LAUNCH_TB
     c->cur ^= 1;
 }
@@ -479,7 +489,7 @@ static int stream_load_slot(deff_ctx *c, int slot, const uint8_t *pix_host)
     hipLaunchKernelGGL(k_wall_D_2phase, dim3((c->ny + 255) / 256), dim3(256), 0, c->stream, dpix, c->W, c->ampX, c->ampY,
                        c->nx, c->ny, c->ny, c->Df, c->Ds, c->Dl + (size_t)slot * c->ny, c->Dr + (size_t)slot * c->ny);
     hipLaunchKernelGGL(k_init_linear, dim3(grid_for(c->n_img)), dim3(256), 0, c->stream,
-                       c->x[c->cur] + (size_t)slot * c->n_img, c->nx, c->ny, c->CL, c->CR);
+                       c->x[c->cur] + (size_t)slot * c->n_img, c->nx, c->ny, c->CL, c->CR, c->fma);
     HIP_TRY(hipGetLastError());
     c->buf_of[slot] = (uint8_t)c->cur;
     return DEFF_OK;

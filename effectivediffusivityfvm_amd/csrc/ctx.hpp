@@ -124,6 +124,7 @@ struct deff_ctx {
     unsigned long long *tb_stamps = nullptr;     // diagnostics: per wave-tile start/end clocks (deff_debug_tb_stamps)
     int tb_wall_halo = 2;                        // strip placement: 1 = halo also outside the walls, 0 = not, 2 = whichever needs fewer strips
     int plan_T = 0, plan_LY = 0, plan_ntx = 0, plan_cpi = 0, plan_blocks = 0;   // last temporally blocked plan
+    int fma = 0;                                 // contracted arithmetic (kernels_sweep.hpp), opt-in
     int tb_xmajor = 1;                           // wave-tile numbering of the temporally blocked kernel
     int64_t last_launches = 0;                   // sweep-kernel launches of the last deff_sweeps()/deff_solve()
 };
@@ -201,6 +202,7 @@ struct SweepPlan {
     double omw = 0;
     int rows = 0, cpi = 0, gx = 0, gy = 0, blocks = 0;   // single-sweep kernels (cpi: row tiles per image)
     // temporally blocked kernel
+    bool fma = false;
     int T = 0, CPL = 2, LY = 0, tcpi = 0, ntx = 0, tgx = 0, tgy = 0, tblocks = 0;
     int shift = 0;                                        // column shift of the strips (0: no halo outside the walls)
     int T_override = 0;                                   // slab mode plans a T = 1 pass for remainders

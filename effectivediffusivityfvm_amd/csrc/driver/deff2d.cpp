@@ -9,6 +9,9 @@
 // --field-bin dumps the FP64 concentration field.
 //
 //   deff2d [input.txt] [--device N | --devices 0,1,..] [--json results.json] [--field-bin prefix] [--batch-size B]
+//          [--progress file] [--arith reference|contracted]
+// --arith contracted: products fused into adds the way a compiler contracts the reference's expressions
+// (kernels_sweep.hpp); default is the reference's written operation order.
 //
 // --devices: batch mode over several GPUs from one process -- one host thread and one solver context
 // per listed device, images handed out from a shared counter, no inter-GPU communication.
@@ -99,6 +102,8 @@ static std::vector<unsigned int> grid_of(const Image &im, const Options &o, int 
     return g;
 }
 
+static int g_contracted = 0;       // --arith contracted: deff_set_tuning(ctx, "fma", 1) on every context
+
 struct Session {                   // one solver context, re-created only when the mesh / batch size changes
     deff_ctx *ctx = nullptr;
     int nx = 0, ny = 0, nimg = 0, device = 0;
@@ -109,6 +114,7 @@ struct Session {                   // one solver context, re-created only when t
         deff_destroy(ctx);
         ctx = nullptr;
         CK(deff_create_batch(device, nx_, ny_, nimg_, &ctx));
+        CK(deff_set_tuning(ctx, "fma", g_contracted));
         nx = nx_; ny = ny_; nimg = nimg_;
         return true;
     }
@@ -491,8 +497,14 @@ int main(int argc, char **argv)
         else if (s == "--field-bin" && a + 1 < argc) field_prefix = argv[++a];
         else if (s == "--batch-size" && a + 1 < argc) batch_size = std::atoi(argv[++a]);
         else if (s == "--progress" && a + 1 < argc) progress_path = argv[++a];
+        else if (s == "--arith" && a + 1 < argc) {
+            const std::string v = argv[++a];
+            if (v == "contracted" || v == "fma") g_contracted = 1;
+            else if (v == "reference" || v == "plain") g_contracted = 0;
+            else { std::fprintf(stderr, "deff2d: --arith takes 'reference' or 'contracted'\n"); return 2; }
+        }
         else if (s == "-h" || s == "--help") {
-            std::printf("usage: deff2d [input.txt] [--device N] [--json results.json] [--field-bin prefix] [--batch-size B] [--devices 0,1,...] [--progress file]\n");
+            std::printf("usage: deff2d [input.txt] [--device N] [--json results.json] [--field-bin prefix] [--batch-size B] [--devices 0,1,...] [--progress file] [--arith reference|contracted]\n");
             return 0;
         } else if (!s.empty() && s[0] != '-') input = s;
         else { std::fprintf(stderr, "deff2d: unknown argument %s\n", s.c_str()); return 2; }
@@ -562,7 +574,8 @@ int main(int argc, char **argv)
             long long want = batch_size > 0 ? batch_size : (big >= 1 && per_dev >= 3 * big ? big : small);
             want = std::min<long long>(want, std::max<long long>(1, per_dev));
             const int slots = (int)std::min<long long>(want, 4096);
-            if (deff_create_batch(dev, nx, ny, slots, &st.ctx) != DEFF_OK) {
+            if (deff_create_batch(dev, nx, ny, slots, &st.ctx) != DEFF_OK ||
+                deff_set_tuning(st.ctx, "fma", g_contracted) != DEFF_OK) {
                 std::fprintf(stderr, "deff2d: %s\n", deff_last_error());
                 failed = true;
                 return;

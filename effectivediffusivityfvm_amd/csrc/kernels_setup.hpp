@@ -201,14 +201,15 @@ static __global__ void k_make_c0(const double *__restrict__ a0, double w, double
 
 // ---------------------------------------------------------------- field ---
 
-// Linear ramp, cuh:1955-1959: (double)j/nx*(CR-CL)+CL.
-static __global__ void k_init_linear(double *__restrict__ x, int nx, int rows, double CL, double CR)
+// Linear ramp, cuh:1955-1959: (double)j/nx*(CR-CL)+CL; `contracted` = the product fused into the
+// add, as in the contracted build of the reference's expression (see kernels_sweep.hpp, FMA).
+static __global__ void k_init_linear(double *__restrict__ x, int nx, int rows, double CL, double CR, int contracted)
 {
     const size_t n = (size_t)nx * rows;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
          p += (size_t)gridDim.x * blockDim.x) {
         int j = (int)(p % nx);
-        x[p] = (double)j / nx * (CR - CL) + CL;
+        x[p] = contracted ? __builtin_fma((double)j / nx, (CR - CL), CL) : (double)j / nx * (CR - CL) + CL;
     }
 }
 

@@ -8,6 +8,14 @@
 // finite x.  The library is compiled with -ffp-contract=off, so no product is
 // fused into an add: results are bit-identical to the CPU oracle.
 //
+// FMA = false is that arithmetic (the default).  FMA = true is the SAME expression as a compiler
+// contracts it when allowed to (gcc -mfma -ffp-contract=fast on the reference's source; nvcc's
+// default -fmad=true is the same kind of transformation): every `sigma += a*x` becomes
+// fma(a, x, sigma) and the final sum becomes fma(1-w, x, (w/A0)*(b - sigma)).  It is bit-identical
+// to the oracle's "fma" build (oracle/Makefile), reproduces the second Deff value the survey
+// recorded for the reference and needs 7 instead of 11 FP64 instructions
+// per cell.  Opt-in: deff_set_tuning(ctx, "fma", 1).
+//
 // Neighbour addressing is the reference's linear one (x[p-1], x[p+1],
 // x[p+nx], x[p-nx]); a neighbour whose linear index falls outside [0, n) is
 // never dereferenced (the reference relies on the zero coefficient there).
@@ -30,16 +38,25 @@ struct CoefConst {
     const double *c0, *aW, *aE, *aS, *aN, *b;
 };
 
+template <bool FMA>
+__device__ __forceinline__ double mul_add(double a, double x, double acc)
+{
+    if constexpr (FMA) return __builtin_fma(a, x, acc);
+    else return acc + a * x;
+}
+
+template <bool FMA>
 __device__ __forceinline__ double jacobi_cell(double c0, double aW, double aE, double aS, double aN,
                                               double b, double xc, double xw, double xe, double xs,
                                               double xn, double omw)
 {
     double sigma = 0;
-    if (aW != 0) sigma += aW * xw;
-    if (aE != 0) sigma += aE * xe;
-    if (aS != 0) sigma += aS * xs;
-    if (aN != 0) sigma += aN * xn;
-    return omw * xc + c0 * (b - sigma);
+    if (aW != 0) sigma = mul_add<FMA>(aW, xw, sigma);
+    if (aE != 0) sigma = mul_add<FMA>(aE, xe, sigma);
+    if (aS != 0) sigma = mul_add<FMA>(aS, xs, sigma);
+    if (aN != 0) sigma = mul_add<FMA>(aN, xn, sigma);
+    if constexpr (FMA) return __builtin_fma(omw, xc, c0 * (b - sigma));
+    else return omw * xc + c0 * (b - sigma);
 }
 
 // Workgroup -> tile map.  Workgroups are dealt round-robin over the 8 XCDs, so
@@ -77,7 +94,7 @@ __device__ __forceinline__ double ldc(const double *p)
     else return *p;
 }
 
-template <bool NT>
+template <bool NT, bool FMA>
 __global__ __launch_bounds__(256) void k_sweep_scalar(CoefConst c, const double *__restrict__ x,
                                                       double *__restrict__ xnew, int nx, size_t n,
                                                       size_t n_img, const uint8_t *__restrict__ active,
@@ -90,8 +107,8 @@ __global__ __launch_bounds__(256) void k_sweep_scalar(CoefConst c, const double 
     const double xe = (p + 1 < n) ? x[p + 1] : 0.0;
     const double xs = (p + nx < n) ? x[p + nx] : 0.0;
     const double xn = (p >= (size_t)nx) ? x[p - nx] : 0.0;
-    xnew[p] = jacobi_cell(ldc<NT>(c.c0 + p), ldc<NT>(c.aW + p), ldc<NT>(c.aE + p), ldc<NT>(c.aS + p),
-                          ldc<NT>(c.aN + p), ldc<NT>(c.b + p), x[p], xw, xe, xs, xn, omw);
+    xnew[p] = jacobi_cell<FMA>(ldc<NT>(c.c0 + p), ldc<NT>(c.aW + p), ldc<NT>(c.aE + p), ldc<NT>(c.aS + p),
+                               ldc<NT>(c.aN + p), ldc<NT>(c.b + p), x[p], xw, xe, xs, xn, omw);
 }
 
 // ----------------------------------------------------------- explicit -----
@@ -124,7 +141,7 @@ __device__ __forceinline__ double2 ldc2(const double *p)
 // Batches (see kernels_setup.hpp): `ny` rows per image, `rows` stacked rows, `cpi` row
 // tiles per image (tiles never straddle two images); `active` (may be null) marks the
 // images still being iterated.
-template <int R, bool NT>
+template <int R, bool NT, bool FMA>
 __global__ __launch_bounds__(256) void k_sweep_explicit(CoefConst c, const double *__restrict__ x,
                                                         double *__restrict__ xnew, int nx, int ny,
                                                         int rows, int cpi,
@@ -165,8 +182,8 @@ __global__ __launch_bounds__(256) void k_sweep_explicit(CoefConst c, const doubl
         const double2 aS = ldc2<NT>(c.aS + p), aN = ldc2<NT>(c.aN + p), b = ldc2<NT>(c.b + p);
         const double2 xm = xr[k], xc = xr[k + 1], xp = xr[k + 2];
         double2 o;
-        o.x = jacobi_cell(c0.x, aW.x, aE.x, aS.x, aN.x, b.x, xc.x, xw[k], xc.y, xp.x, xm.x, omw);
-        o.y = jacobi_cell(c0.y, aW.y, aE.y, aS.y, aN.y, b.y, xc.y, xc.x, xe[k], xp.y, xm.y, omw);
+        o.x = jacobi_cell<FMA>(c0.x, aW.x, aE.x, aS.x, aN.x, b.x, xc.x, xw[k], xc.y, xp.x, xm.x, omw);
+        o.y = jacobi_cell<FMA>(c0.y, aW.y, aE.y, aS.y, aN.y, b.y, xc.y, xc.x, xe[k], xp.y, xm.y, omw);
         st2(xnew + p, o);
     }
 }
@@ -175,15 +192,16 @@ __global__ __launch_bounds__(256) void k_sweep_explicit(CoefConst c, const doubl
 
 // One cell from the row dictionary (lut_layout.hpp); `off` is the cell's code = byte offset of
 // its row inside a plane.
+template <bool FMA>
 __device__ __forceinline__ double jacobi_cell_lut(const double *lut, unsigned off, double xc, double xw,
                                                   double xe, double xs, double xn, double omw)
 {
     const char *base = reinterpret_cast<const char *>(lut) + off;
     constexpr int PS = LUT_PLANE_STRIDE * 8;
-    return jacobi_cell(*reinterpret_cast<const double *>(base), *reinterpret_cast<const double *>(base + PS),
-                       *reinterpret_cast<const double *>(base + 2 * PS), *reinterpret_cast<const double *>(base + 3 * PS),
-                       *reinterpret_cast<const double *>(base + 4 * PS), *reinterpret_cast<const double *>(base + 5 * PS),
-                       xc, xw, xe, xs, xn, omw);
+    return jacobi_cell<FMA>(*reinterpret_cast<const double *>(base), *reinterpret_cast<const double *>(base + PS),
+                            *reinterpret_cast<const double *>(base + 2 * PS), *reinterpret_cast<const double *>(base + 3 * PS),
+                            *reinterpret_cast<const double *>(base + 4 * PS), *reinterpret_cast<const double *>(base + 5 * PS),
+                            xc, xw, xe, xs, xn, omw);
 }
 
 // Copy the first `nrows` rows of every plane of the dictionary into LDS (workgroup-wide).
@@ -208,7 +226,7 @@ __device__ __forceinline__ void tile_coords(unsigned t, int gy, int &bx, int &by
 // VEC = 2 needs nx even; VEC = 1 handles any nx.  Tile = 256*VEC columns x R
 // rows.  Position classes are folded into the codes at assembly, the kernel only looks rows up.  Persistent: the grid is a few workgroups per CU, each loads the tables
 // into LDS once and then walks its share of the tiles.
-template <int VEC, int R>
+template <int VEC, int R, bool FMA>
 __global__ __launch_bounds__(256) void k_sweep_matfree(const double *__restrict__ lut_g,
                                                        const uint16_t *__restrict__ code,
                                                        const double *__restrict__ x,
@@ -265,8 +283,8 @@ __global__ __launch_bounds__(256) void k_sweep_matfree(const double *__restrict_
                 const unsigned i0 = cc[q] & 0xFFFFu, i1 = cc[q] >> 16;
                 const double2 xm = xr[q], xc = xr[q + 1], xp = xr[q + 2];
                 double2 o;
-                o.x = jacobi_cell_lut(lut, i0, xc.x, xw[q], xc.y, xp.x, xm.x, omw);
-                o.y = jacobi_cell_lut(lut, i1, xc.y, xc.x, xe[q], xp.y, xm.y, omw);
+                o.x = jacobi_cell_lut<FMA>(lut, i0, xc.x, xw[q], xc.y, xp.x, xm.x, omw);
+                o.y = jacobi_cell_lut<FMA>(lut, i1, xc.y, xc.x, xe[q], xp.y, xm.y, omw);
                 st2(xnew + p, o);
             }
         } else {
@@ -291,7 +309,7 @@ __global__ __launch_bounds__(256) void k_sweep_matfree(const double *__restrict_
                 if (r >= rlim) break;
                 const size_t p = p0 + (size_t)q * nx;
                 const unsigned i0 = cc[q];
-                xnew[p] = jacobi_cell_lut(lut, i0, xr[q + 1], xw[q], xe[q], xr[q + 2], xr[q], omw);
+                xnew[p] = jacobi_cell_lut<FMA>(lut, i0, xr[q + 1], xw[q], xe[q], xr[q + 2], xr[q], omw);
             }
         }
     }

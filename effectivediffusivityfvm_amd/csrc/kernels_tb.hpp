@@ -58,7 +58,7 @@ __device__ __forceinline__ double from_lane_above(double v)
 // unchanged, so both forms give the same bits.  WALL = the strip contains the
 // first or last column; everywhere else b is identically +0.0 and its lookup is
 // skipped (0.0 - sigma is still evaluated as a subtraction, so the bits match).
-template <bool GUARD, bool WALL>
+template <bool GUARD, bool WALL, bool FMA>
 __device__ __forceinline__ double tb_cell(const double *lut, unsigned off, double xc, double xw, double xe,
                                           double xs, double xn, double omw)
 {
@@ -72,15 +72,17 @@ __device__ __forceinline__ double tb_cell(const double *lut, unsigned off, doubl
     double b = 0.0;
     if constexpr (WALL) b = *reinterpret_cast<const double *>(base + 5 * PS);
     if constexpr (GUARD) {
-        return jacobi_cell(c0, aW, aE, aS, aN, b, xc, xw, xe, xs, xn, omw);
+        return jacobi_cell<FMA>(c0, aW, aE, aS, aN, b, xc, xw, xe, xs, xn, omw);
     } else {
         // the reference starts from sigma = 0 (cuh:74); 0 + p differs from p only in the sign of a
         // zero, which b - sigma cannot see (b is +0 or non-zero), so the leading add is dropped
+        // (in the contracted form the first term is fma(aW, xw, 0) = the rounded product, likewise)
         double sigma = aW * xw;
-        sigma += aE * xe;
-        sigma += aS * xs;
-        sigma += aN * xn;
-        return omw * xc + c0 * (b - sigma);
+        sigma = mul_add<FMA>(aE, xe, sigma);
+        sigma = mul_add<FMA>(aS, xs, sigma);
+        sigma = mul_add<FMA>(aN, xn, sigma);
+        if constexpr (FMA) return __builtin_fma(omw, xc, c0 * (b - sigma));
+        else return omw * xc + c0 * (b - sigma);
     }
 }
 
@@ -104,7 +106,7 @@ __device__ __forceinline__ double tb_cell(const double *lut, unsigned off, doubl
 // the lookups' latency matters, not their number.  The
 // code is deliberately written with double2 values and named slots: an array-of-scalars
 // formulation of the same dataflow made hipcc hoist the lookups to 204 VGPRs.)
-template <int T, bool GUARD, bool WALL>
+template <int T, bool GUARD, bool WALL, bool FMA>
 __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__restrict__ code,
                                          const double *__restrict__ x, double *__restrict__ xnew, int nx,
                                          int ny, int row_lo, int own_hi, int tx, int ntx, int shift, int ry0, int LY,
@@ -187,8 +189,8 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
                 const double xe1 = from_lane_above(vC.x);
                 const unsigned o0 = cw[t] & 0xFFFFu, o1 = cw[t] >> 16;
                 double2 o;
-                o.x = tb_cell<GUARD, WALL>(lut, o0, vC.x, xw0, vC.y, vS.x, vN.x, omw);
-                o.y = tb_cell<GUARD, WALL>(lut, o1, vC.y, vC.x, xe1, vS.y, vN.y, omw);
+                o.x = tb_cell<GUARD, WALL, FMA>(lut, o0, vC.x, xw0, vC.y, vS.x, vN.x, omw);
+                o.y = tb_cell<GUARD, WALL, FMA>(lut, o1, vC.y, vC.x, xe1, vS.y, vN.y, omw);
                 if (t < T) {
                     w[t][sS] = o;
                 } else if (st_x && rt >= ry0 && rt < ry1) {
@@ -212,7 +214,7 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
 // [own_lo + k*img_stride, ... + own_h).  Batch: dom_lo = own_lo = 0, own_h = img_stride = ny.
 // Row slab (one image): dom_lo = -(first array row's global index), ny = global height,
 // own_lo = halo depth, own_h = rows owned by this rank.
-template <int T, int CPL, bool GUARD>
+template <int T, bool FMA, bool GUARD>
 __global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restrict__ lut_g,
                                                           const uint16_t *__restrict__ code,
                                                           const double *__restrict__ x,
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restri
                                                           int xmajor, int allb, int nrows, int shift,
                                                           double omw, unsigned long long *__restrict__ stamps)
 {
-    static_assert(T >= 1 && T <= 8 && CPL == 2, "unsupported T / cells per lane");
+    static_assert(T >= 1 && T <= 8, "unsupported T");
     __shared__ double lut[LUT_DOUBLES];
     load_lut(lut, lut_g, nrows);
 
@@ -259,9 +261,9 @@ __global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restri
         // b is read only where it can be non-zero: strips holding a wall column, or everywhere for a
         // harvested dictionary whose right-hand side is not confined to the walls
         if (allb || tx == 0 || tx == ntx - 1)
-            tb_strip<T, GUARD, true>(lut, code, x, xnew, nx, ny, row_lo, own0 + own_h, tx, ntx, shift, ry0, LY, lane, omw);
+            tb_strip<T, GUARD, true, FMA>(lut, code, x, xnew, nx, ny, row_lo, own0 + own_h, tx, ntx, shift, ry0, LY, lane, omw);
         else
-            tb_strip<T, GUARD, false>(lut, code, x, xnew, nx, ny, row_lo, own0 + own_h, tx, ntx, shift, ry0, LY, lane, omw);
+            tb_strip<T, GUARD, false, FMA>(lut, code, x, xnew, nx, ny, row_lo, own0 + own_h, tx, ntx, shift, ry0, LY, lane, omw);
         if (stamps && lane == 0) {
             stamps[2 * (size_t)wt] = t_begin;
             stamps[2 * (size_t)wt + 1] = wall_clock64();

@@ -105,9 +105,9 @@ def fill_D_3phase(pix, DCF, DCS, DCG, ampX=1, ampY=1):
     return D
 
 
-def linear_guess(nx, ny, CL, CR):
+def linear_guess(nx, ny, CL, CR, flavour=None):
     x = np.empty((ny, nx), dtype=np.float64)
-    lib().oracle_linear_guess(x, nx, ny, CL, CR)
+    lib(flavour).oracle_linear_guess(x, nx, ny, CL, CR)
     return x
 
 
@@ -124,11 +124,11 @@ def discretize(D, CL, CR, grid=None):
     return A, b
 
 
-def sweeps(A, b, x, nsweeps, kernel=0, omega=OMEGA_REF):
+def sweeps(A, b, x, nsweeps, kernel=0, omega=OMEGA_REF, flavour=None):
     ny, nx = x.shape
     x = np.array(x, dtype=np.float64, order="C", copy=True)
     tmp = np.empty_like(x)
-    lib().oracle_sweeps(A, b, x, tmp, nx, ny, nsweeps, kernel, omega)
+    lib(flavour).oracle_sweeps(A, b, x, tmp, nx, ny, nsweeps, kernel, omega)
     return x
 
 

@@ -137,7 +137,14 @@ def test_driver_2phase_batch_config1(built, tmp_path, recorded):
     res = json.load(open(tmp_path / "res.json"))["results"][0]
     rec = recorded["img00000_2phase_batch"]
     assert res["iterations"] == rec["iters"] and res["porosity"] == rec["porosity"] and res["PathFlag"] == 1
-    assert res["Deff"] in (rec["deff_build_a"], rec["deff_build_b"])
+    assert res["Deff"] == rec["deff_build_b"]              # the reference's written operation order
+    # --arith contracted: the survey's other host build of the reference, Deff and conv to the last digit
+    r = subprocess.run([EXE, "input.txt", "--json", "res_c.json", "--arith", "contracted"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    res_c = json.load(open(tmp_path / "res_c.json"))["results"][0]
+    assert res_c["iterations"] == rec["iters"] and res_c["Deff"] == rec["deff_build_a"]
+    assert res_c["converge"] == rec["conv_build_a"]
     rows = open(tmp_path / "out.csv").read().splitlines()
     assert rows[0] == "imgNum,porosity,PathFlag,Deff,Time,nElements,converge,ds,df"
     cols = rows[1].split(",")

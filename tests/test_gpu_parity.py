@@ -540,6 +540,77 @@ def test_slab_ranks_three_processes_one_gpu(pkg, oracle, tmp_path):
         assert np.array_equal(np.load(tmp_path / f"mfl{k}.npy"), MFL)
 
 
+# ---- contracted arithmetic (opt-in): the oracle's "fma" build is the checker ------------------
+
+@pytest.mark.parametrize("kernel,nx,ny", [("explicit", 96, 64), ("scalar", 97, 41), ("matfree", 96, 64),
+                                          ("matfree", 97, 41), ("matfree_tb", 260, 70)])
+def test_fma_mode_matches_contracted_oracle(pkg, oracle, kernel, nx, ny):
+    """deff_set_tuning("fma", 1): every sweep kernel (and the linear guess) is bit-identical to the
+    oracle built with contraction allowed -- and differs from the default arithmetic, so the switch
+    is really exercised."""
+    rng = np.random.default_rng(21)
+    pix = rand_mask(rng, nx, ny, 0.45)
+    CL, CR = 0.1, 0.93
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-2)
+    A, b = oracle.discretize(D, CL, CR)
+    x0 = oracle.linear_guess(nx, ny, CL, CR, flavour="fma")
+    nsw = 37
+    ref = oracle.sweeps(A, b, x0, nsw, flavour="fma")
+    plain = oracle.sweeps(A, b, oracle.linear_guess(nx, ny, CL, CR), nsw)
+    assert not np.array_equal(ref, plain)
+    with pkg.Solver(nx, ny, kernel=kernel) as s:
+        s.set_tuning("fma", 1)
+        s.set_image(pix)
+        s.assemble_2phase(1e-2, 1.0, CL, CR)
+        s.init_linear(CL, CR)
+        assert np.array_equal(s.get_field(), x0)
+        s.sweeps(nsw)
+        assert s.kernel_in_use() == kernel
+        assert_field(s.get_field(), ref)
+        s.set_tuning("fma", 0)                       # and back: the default arithmetic again
+        s.init_linear(CL, CR)
+        s.sweeps(nsw)
+        assert_field(s.get_field(), plain)
+
+
+def test_fma_mode_three_phase_guarded_rows(pkg, oracle):
+    """Zero-diffusivity solid (links -0.0, NaN-free thanks to the guard) through the dictionary and the
+    temporally blocked kernel in contracted arithmetic."""
+    rng = np.random.default_rng(22)
+    nx, ny = 192, 80
+    pix = rng.choice(np.array([0, 120, 255], dtype=np.uint8), size=(ny, nx), p=[0.3, 0.4, 0.3])
+    D = oracle.fill_D_3phase(pix, 1.0, 0.0, 50.0)
+    grid = (pix > 200).astype(np.uint32)
+    A, b = oracle.discretize(D, 0.0, 1.0, grid=grid)
+    x0 = oracle.linear_guess(nx, ny, 0.0, 1.0, flavour="fma")
+    ref = oracle.sweeps(A, b, x0, 29, flavour="fma")
+    for kernel in ("auto", "explicit"):
+        with pkg.Solver(nx, ny, kernel=kernel) as s:
+            s.set_tuning("fma", 1)
+            s.set_image(pix)
+            s.assemble_3phase(0.0, 1.0, 50.0, 0.0, 1.0, grid=grid)
+            s.init_linear(0.0, 1.0)
+            s.sweeps(29)
+            assert s.kernel_in_use() == ("matfree_tb" if kernel == "auto" else "explicit")
+            assert_field(s.get_field(), ref)
+
+
+def test_fma_mode_config1_gives_the_surveys_primary_value(pkg, oracle, recorded, img00000):
+    """Config #1 end to end in contracted arithmetic: 110 001 sweeps and the Deff / conv the survey
+    recorded first for the reference (build a); the default arithmetic gives build b
+    (test_img00000_config1_end_to_end)."""
+    rec = recorded["img00000_2phase_batch"]
+    with pkg.Solver(128, 128) as s:
+        s.set_tuning("fma", 1)
+        s.set_image(img00000)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        r = s.solve(1e-6, 500000)
+    assert r.iters == rec["iters"]
+    assert r.deff_raw == rec["deff_build_a"]
+    assert r.conv == rec["conv_build_a"]
+
+
 def test_host_assembled_system_drop_in(pkg, oracle):
     """The reference's own arrays (A AoS, b, D) go in unchanged: set_system + solve."""
     rng = np.random.default_rng(11)
