@@ -75,7 +75,13 @@ int deff_destroy(deff_ctx *ctx);
 int deff_mesh(const deff_ctx *ctx, int *nx, int *ny, double *dx, double *dy);   /* meshInfo cuh:54-61 */
 int deff_set_kernel(deff_ctx *ctx, int kernel);
 int deff_get_kernel(const deff_ctx *ctx, int *kernel_in_use);
-/* tuning knob (rows marched per workgroup etc.); 0 restores the default */
+/* tuning knob; 0 restores the default.  Keys: "rows_explicit", "rows_matfree", "wg_matfree",
+ * "nt_explicit", "serpentine", "tb_T" (sweeps per pass: 1,2,4,6,8), "tb_LY" (rows per chunk), "tb_wg",
+ * "tb_xmajor", "tb_wall_halo", "dict" (harvest a row dictionary from explicit systems: 1 default), and
+ *   "fma" = 1: contracted arithmetic -- the reference's expressions (cuh:74-89, cuh:1957) with each
+ *   product fused into the following add, as nvcc's default -fmad=true / gcc -ffp-contract=fast compile
+ *   them; bit-identical to the oracle's fma build, not to the default (written-order) arithmetic.
+ *   Set it before deff_init_linear(); it applies to every sweep kernel. */
 int deff_set_tuning(deff_ctx *ctx, const char *key, int value);
 /* what the last launch plan of the temporally blocked kernel chose: "tb_T", "tb_LY" (rows per chunk),
  * "tb_strips", "tb_chunks_per_image", "tb_blocks" (workgroups launched); 0 before any sweep */
