@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libdeff_amd.so")
+# DEFF_AMD_LIB: another build of the same library (kernel experiments, A/B runs on one box)
+LIB_PATH = os.environ.get("DEFF_AMD_LIB") or os.path.join(_PKG, "libdeff_amd.so")
 
 KERNEL_AUTO, KERNEL_EXPLICIT, KERNEL_SCALAR, KERNEL_MATFREE, KERNEL_MATFREE_TB = range(5)
 KERNEL_NAMES = {"auto": 0, "explicit": 1, "scalar": 2, "matfree": 3, "matfree_tb": 4}

@@ -103,7 +103,12 @@ __device__ __forceinline__ double tb_cell(const double *lut, unsigned off, doubl
 // aS(r-1): take aE from the lane's other cell / the next lane by DPP and carry aS down one step;
 // 6 instead of 10 ds_read_b64 per lane and level) -- +4 % at T=4, +5 % at T=6, 0 at T=8 where the
 // carried values cost a wave of occupancy: the LDS (CDNA4: 2 clocks per ds_read_b64) is ~45 % busy,
-// the lookups' latency matters, not their number.  The
+// the lookups' latency matters, not their number; the four links a level needs first (aW, aE of both
+// cells) looked up one level ahead inside the occupancy budget (+8 VGPRs: 158/136/114 at T=8/6/4) --
+// 0-3 %.  What bounds the kernel (tools/ubench): an FP64 instruction with VGPR-pair sources issues once
+// per 8 clocks from ONE wave whatever the ILP, and reaches the 4-clock rate only with two waves of
+// the SIMD ready at once -- with 3-4 resident waves that are parked on LDS part of the time, the
+// SIMD sees one or two.  Only more resident waves would help, and the registers are spent.  The
 // code is deliberately written with double2 values and named slots: an array-of-scalars
 // formulation of the same dataflow made hipcc hoist the lookups to 204 VGPRs.)
 template <int T, bool GUARD, bool WALL, bool FMA>

@@ -66,6 +66,47 @@ __global__ __launch_bounds__(256) void k_lds(double *out, int iters)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// VGPR bank test: v_mul_f64 / v_fma_f64 with explicit registers.  MODE 0: the two (three) source pairs
+// sit in different register banks (pair index mod 2 differs: v[8:9] x v[10:11]); MODE 1: all sources
+// in the same banks (v[8:9] x v[12:13]); destinations rotate over v[40..55].
+template <int MODE, int FMA3>
+__global__ __launch_bounds__(256) void k_banks(double *out, int iters)
+{
+    double acc = 0;
+    asm volatile("v_mov_b32 v8, 1.0\n v_mov_b32 v9, 1.0\n v_mov_b32 v10, 1.0\n v_mov_b32 v11, 1.0\n"
+                 "v_mov_b32 v12, 1.0\n v_mov_b32 v13, 1.0\n v_mov_b32 v14, 1.0\n v_mov_b32 v15, 1.0\n"
+                 "v_mov_b32 v16, 1.0\n v_mov_b32 v17, 1.0\n v_mov_b32 v20, 1.0\n v_mov_b32 v21, 1.0\n"
+                 ::: "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v20", "v21");
+    for (int i = 0; i < iters; ++i) {
+        if (FMA3 == 0 && MODE == 0)
+            asm volatile("v_mul_f64 v[40:41], v[8:9], v[10:11]\n v_mul_f64 v[42:43], v[12:13], v[14:15]\n"
+                         "v_mul_f64 v[44:45], v[8:9], v[14:15]\n v_mul_f64 v[46:47], v[12:13], v[10:11]\n"
+                         "v_mul_f64 v[48:49], v[8:9], v[10:11]\n v_mul_f64 v[50:51], v[12:13], v[14:15]\n"
+                         "v_mul_f64 v[52:53], v[8:9], v[14:15]\n v_mul_f64 v[54:55], v[12:13], v[10:11]\n"
+                         ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+        if (FMA3 == 0 && MODE == 1)
+            asm volatile("v_mul_f64 v[40:41], v[8:9], v[12:13]\n v_mul_f64 v[42:43], v[12:13], v[16:17]\n"
+                         "v_mul_f64 v[44:45], v[8:9], v[16:17]\n v_mul_f64 v[46:47], v[12:13], v[20:21]\n"
+                         "v_mul_f64 v[48:49], v[8:9], v[12:13]\n v_mul_f64 v[50:51], v[12:13], v[16:17]\n"
+                         "v_mul_f64 v[52:53], v[8:9], v[16:17]\n v_mul_f64 v[54:55], v[12:13], v[20:21]\n"
+                         ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+        if (FMA3 == 1 && MODE == 0)   // three sources, banks (0,1) (2,3) (0,1)
+            asm volatile("v_fma_f64 v[40:41], v[8:9], v[10:11], v[12:13]\n v_fma_f64 v[42:43], v[12:13], v[14:15], v[8:9]\n"
+                         "v_fma_f64 v[44:45], v[8:9], v[14:15], v[16:17]\n v_fma_f64 v[46:47], v[12:13], v[10:11], v[20:21]\n"
+                         "v_fma_f64 v[48:49], v[8:9], v[10:11], v[12:13]\n v_fma_f64 v[50:51], v[12:13], v[14:15], v[8:9]\n"
+                         "v_fma_f64 v[52:53], v[8:9], v[14:15], v[16:17]\n v_fma_f64 v[54:55], v[12:13], v[10:11], v[20:21]\n"
+                         ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+        if (FMA3 == 1 && MODE == 1)   // three sources, all in banks (0,1)
+            asm volatile("v_fma_f64 v[40:41], v[8:9], v[12:13], v[16:17]\n v_fma_f64 v[42:43], v[12:13], v[16:17], v[20:21]\n"
+                         "v_fma_f64 v[44:45], v[8:9], v[16:17], v[20:21]\n v_fma_f64 v[46:47], v[12:13], v[20:21], v[8:9]\n"
+                         "v_fma_f64 v[48:49], v[8:9], v[12:13], v[16:17]\n v_fma_f64 v[50:51], v[12:13], v[16:17], v[20:21]\n"
+                         "v_fma_f64 v[52:53], v[8:9], v[16:17], v[20:21]\n v_fma_f64 v[54:55], v[12:13], v[20:21], v[8:9]\n"
+                         ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+    }
+    asm volatile("v_mov_b32 %0, v40" : "=v"(*(int *)&acc));
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 template <class F>
 static double time_ms(F launch)
 {
@@ -105,6 +146,10 @@ int main()
         report("v_mul_f64 (8 chains)", time_ms([&] { hipLaunchKernelGGL(k_valu<1>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.5, 1.0000001); }), 32);
         report("v_fma_f64 (8 chains)", time_ms([&] { hipLaunchKernelGGL(k_valu<2>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.5, 1.0000001); }), 32);
         report("add/mul f64, ONE dependent chain", time_ms([&] { hipLaunchKernelGGL(k_valu<3>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.5, 1.0000001); }), 32);
+        report("v_mul_f64 2 VGPR sources, banks differ", time_ms([&] { hipLaunchKernelGGL((k_banks<0, 0>), dim3(blocks), dim3(256), 0, 0, out, iters * 4); }), 32);
+        report("v_mul_f64 2 VGPR sources, same banks", time_ms([&] { hipLaunchKernelGGL((k_banks<1, 0>), dim3(blocks), dim3(256), 0, 0, out, iters * 4); }), 32);
+        report("v_fma_f64 3 VGPR sources, 2 banks", time_ms([&] { hipLaunchKernelGGL((k_banks<0, 1>), dim3(blocks), dim3(256), 0, 0, out, iters * 4); }), 32);
+        report("v_fma_f64 3 VGPR sources, same banks", time_ms([&] { hipLaunchKernelGGL((k_banks<1, 1>), dim3(blocks), dim3(256), 0, 0, out, iters * 4); }), 32);
         report("v_mov_b32_dpp wave_shr/shl", time_ms([&] { hipLaunchKernelGGL(k_dpp, dim3(blocks), dim3(256), 0, 0, (int *)out, iters); }), 32);
         report("ds_read_b64 consecutive", time_ms([&] { hipLaunchKernelGGL(k_lds<0>, dim3(blocks), dim3(256), 0, 0, out, iters); }), 32);
         report("ds_read_b64 random rows", time_ms([&] { hipLaunchKernelGGL(k_lds<1>, dim3(blocks), dim3(256), 0, 0, out, iters); }), 32);
