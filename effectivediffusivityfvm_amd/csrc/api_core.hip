@@ -68,7 +68,7 @@ try {
     *out = nullptr;
     if (nx < 2 || ny < 2) return fail(DEFF_EINVAL, "mesh must be at least 2x2 (got %dx%d)", nx, ny);
     if (nimg < 1) return fail(DEFF_EINVAL, "batch size must be >= 1 (got %d)", nimg);
-    if ((size_t)nx * (size_t)ny * (size_t)nimg > (size_t)1 << 31 || (long long)ny * nimg > (1ll << 30))
+    if ((size_t)((nx + 1) & ~1) * (size_t)ny * (size_t)nimg > (size_t)1 << 31 || (long long)ny * nimg > (1ll << 30))
         return fail(DEFF_EINVAL, "%d image(s) of %dx%d exceed 2^31 cells", nimg, nx, ny);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -79,8 +79,10 @@ try {
     deff_ctx *c = new (std::nothrow) deff_ctx();
     if (!c) return fail(DEFF_ENOMEM, "host allocation failed");
     c->device = device;
-    c->nx = nx; c->ny = ny; c->nimg = nimg; c->rows = nimg * ny;
-    c->n_img = (size_t)nx * ny; c->n = c->n_img * nimg;
+    c->nxt = nx;
+    c->nx = (nx + 1) & ~1;          // arrays are padded to an even width (16-byte rows)
+    c->ny = ny; c->nimg = nimg; c->rows = nimg * ny;
+    c->n_img = (size_t)c->nx * ny; c->n = c->n_img * nimg;
     c->active_h.assign(nimg, 1); c->buf_of.assign(nimg, 0);
     c->mesh_ny = ny; c->own_h = ny;
     c->dx = 1.0 / nx;           // cuh:1910-1911: the domain is always the unit square
@@ -129,7 +131,7 @@ DEFF_API_CATCH
 extern "C" int deff_mesh(const deff_ctx *c, int *nx, int *ny, double *dx, double *dy)
 try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
-    if (nx) *nx = c->nx;
+    if (nx) *nx = c->nxt;
     if (ny) *ny = c->ny;
     if (dx) *dx = c->dx;
     if (dy) *dy = c->dy;
@@ -172,15 +174,15 @@ int resolve_kernel(const deff_ctx *c, int *k)
         if (!c->have_matfree) {
             // an explicit system without a usable row dictionary stays on the explicit kernels
             if (!c->have_explicit) return fail(DEFF_ESTATE, "no system assembled");
-            want = (c->nx & 1) ? DEFF_KERNEL_SCALAR : DEFF_KERNEL_EXPLICIT;
+            want = DEFF_KERNEL_EXPLICIT;
             *k = want;
             return DEFF_OK;
         }
-        // the temporally blocked kernel needs 16-B aligned strips (even nx) and a few rows to stream
-        if (want == DEFF_KERNEL_MATFREE_TB && ((c->nx & 1) || c->ny < 8)) want = DEFF_KERNEL_MATFREE;
+        // the temporally blocked kernel needs a few rows to stream (rows are always 16-B aligned:
+        // an odd mesh width is padded, ctx.hpp)
+        if (want == DEFF_KERNEL_MATFREE_TB && c->ny < 8) want = DEFF_KERNEL_MATFREE;
     } else {
         if (!c->have_explicit && !c->have_matfree) return fail(DEFF_ESTATE, "no system assembled");
-        if (want == DEFF_KERNEL_EXPLICIT && (c->nx & 1)) want = DEFF_KERNEL_SCALAR;   // 16-B rows need even nx
     }
     *k = want;
     return DEFF_OK;
@@ -234,9 +236,9 @@ int image_shape(deff_ctx *c, int W, int H, int ampX, int ampY)
 {
     if (W < 1 || H < 1 || ampX < 1 || ampY < 1)            // cuh:1901-1904
         return fail(DEFF_EINVAL, "image %dx%d / mesh amplification %dx%d invalid", W, H, ampX, ampY);
-    if ((long long)W * ampX != c->nx || (long long)H * ampY != c->ny)
+    if ((long long)W * ampX != c->nxt || (long long)H * ampY != c->ny)
         return fail(DEFF_EINVAL, "image %dx%d x amp %dx%d does not match mesh %dx%d", W, H, ampX, ampY,
-                    c->nx, c->ny);
+                    c->nxt, c->ny);
     if (c->pix && (c->W != W || c->H != H)) { HIP_TRY(hipFree(c->pix)); c->pix = nullptr; }
     TRY(dev_alloc(&c->pix, (size_t)W * H * c->nimg));
     c->W = W; c->H = H; c->ampX = ampX; c->ampY = ampY;
@@ -260,9 +262,9 @@ extern "C" int deff_synth_image(deff_ctx *c, uint64_t seed, uint64_t img)
 try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     TRY(use_device(c));
-    TRY(image_shape(c, c->nx, c->ny, 1, 1));
+    TRY(image_shape(c, c->nxt, c->ny, 1, 1));
     // stacked rows continue the per-pixel key, so a batch holds images img, img+1, ...
-    hipLaunchKernelGGL(k_synth_mask, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->nx, c->rows,
+    hipLaunchKernelGGL(k_synth_mask, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->nxt, c->rows,
                        seed, img);
     HIP_TRY(hipGetLastError());
     c->have_image = true;
@@ -336,7 +338,7 @@ try {
     TRY(ensure_walls(c));
     c->CL = CL; c->CR = CR;
     hipLaunchKernelGGL(k_wall_D_2phase, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, c->pix, c->W,
-                       c->ampX, c->ampY, c->nx, c->ny, c->rows, Df, Ds, c->Dl, c->Dr);
+                       c->ampX, c->ampY, c->nxt, c->ny, c->rows, Df, Ds, c->Dl, c->Dr);
     HIP_TRY(hipGetLastError());
     c->have_walls = true;
 
@@ -344,7 +346,7 @@ try {
     TRY(dev_alloc(&c->code, c->n));
     c->dict_tried = false;
     hipLaunchKernelGGL(k_phase_codes, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->W, c->ampX,
-                       c->ampY, c->nx, c->ny, c->rows, c->dom_lo, c->mesh_ny, c->code);
+                       c->ampY, c->nx, c->nxt, c->ny, c->rows, c->dom_lo, c->mesh_ny, c->code);
     HIP_TRY(hipGetLastError());
     build_lut_rows(c, Ds, Df, CL, CR);
     c->have_matfree = true;
@@ -367,9 +369,9 @@ int explicit_from_image(deff_ctx *c)
     TRY(ensure_scratch(c, sizeof(double) * c->n));
     double *D = (double *)c->scratch;
     hipLaunchKernelGGL(k_fill_D_2phase, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->W, c->ampX,
-                       c->ampY, c->nx, c->ny, c->rows, c->Df, c->Ds, D);
+                       c->ampY, c->nx, c->nxt, c->ny, c->rows, c->Df, c->Ds, D);
     hipLaunchKernelGGL(k_assemble_from_D, dim3(grid_for(c->n)), dim3(256), 0, c->stream, D,
-                       (const unsigned int *)nullptr, c->nx, c->ny, c->rows, c->dx, c->dy, c->CL, c->CR,
+                       (const unsigned int *)nullptr, c->nx, c->nxt, c->ny, c->rows, c->dx, c->dy, c->CL, c->CR,
                        soa_of(c));
     HIP_TRY(hipGetLastError());
     c->have_explicit = true;
@@ -393,13 +395,16 @@ try {
     TRY(ensure_scratch(c, bytes));
     double *dD = (double *)c->scratch;
     unsigned int *dG = Grid ? (unsigned int *)((char *)c->scratch + sizeof(double) * c->n) : nullptr;
-    if (Grid) HIP_TRY(hipMemcpyAsync(dG, Grid, sizeof(unsigned int) * c->n, hipMemcpyHostToDevice, c->stream));
+    if (Grid) {
+        if (c->nx != c->nxt) HIP_TRY(hipMemsetAsync(dG, 0, sizeof(unsigned int) * c->n, c->stream));
+        TRY(rows_h2d(c, dG, Grid, (size_t)c->rows));
+    }
     c->CL = CL; c->CR = CR;
     hipLaunchKernelGGL(k_fill_D_3phase, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->W, c->ampX,
-                       c->ampY, c->nx, c->ny, c->rows, Df, Ds, Dg, dD);
-    hipLaunchKernelGGL(k_assemble_from_D, dim3(grid_for(c->n)), dim3(256), 0, c->stream, dD, dG, c->nx,
+                       c->ampY, c->nx, c->nxt, c->ny, c->rows, Df, Ds, Dg, dD);
+    hipLaunchKernelGGL(k_assemble_from_D, dim3(grid_for(c->n)), dim3(256), 0, c->stream, dD, dG, c->nx, c->nxt,
                        c->ny, c->rows, c->dx, c->dy, CL, CR, soa_of(c));
-    hipLaunchKernelGGL(k_wall_D_from_D, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, dD, c->nx,
+    hipLaunchKernelGGL(k_wall_D_from_D, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, dD, c->nx, c->nxt,
                        c->rows, c->Dl, c->Dr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));        // Grid may be freed by the caller
@@ -456,12 +461,13 @@ try {
     TRY(ensure_scratch(c, bytes));
     double *dD = (double *)c->scratch;
     unsigned int *dG = Grid ? (unsigned int *)((char *)c->scratch + sizeof(double) * c->n) : nullptr;
-    HIP_TRY(hipMemcpyAsync(dD, D, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
-    if (Grid) HIP_TRY(hipMemcpyAsync(dG, Grid, sizeof(unsigned int) * c->n, hipMemcpyHostToDevice, c->stream));
+    if (c->nx != c->nxt) HIP_TRY(hipMemsetAsync(c->scratch, 0, bytes, c->stream));
+    TRY(rows_h2d(c, dD, D, (size_t)c->rows));
+    if (Grid) TRY(rows_h2d(c, dG, Grid, (size_t)c->rows));
     c->CL = CL; c->CR = CR;
-    hipLaunchKernelGGL(k_assemble_from_D, dim3(grid_for(c->n)), dim3(256), 0, c->stream, dD, dG, c->nx,
+    hipLaunchKernelGGL(k_assemble_from_D, dim3(grid_for(c->n)), dim3(256), 0, c->stream, dD, dG, c->nx, c->nxt,
                        c->ny, c->rows, c->dx, c->dy, CL, CR, soa_of(c));
-    hipLaunchKernelGGL(k_wall_D_from_D, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, dD, c->nx,
+    hipLaunchKernelGGL(k_wall_D_from_D, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, dD, c->nx, c->nxt,
                        c->rows, c->Dl, c->Dr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -478,24 +484,30 @@ try {
     TRY(use_device(c));
     TRY(ensure_explicit(c));
     TRY(ensure_scratch(c, sizeof(double) * 5 * CHUNK_CELLS));
-    for (size_t first = 0; first < c->n; first += CHUNK_CELLS) {
-        const size_t cnt = (c->n - first < CHUNK_CELLS) ? c->n - first : CHUNK_CELLS;
+    const size_t n_mesh = (size_t)c->nxt * c->rows;       // cells of the caller's arrays
+    for (size_t first = 0; first < n_mesh; first += CHUNK_CELLS) {
+        const size_t cnt = (n_mesh - first < CHUNK_CELLS) ? n_mesh - first : CHUNK_CELLS;
         HIP_TRY(hipMemcpyAsync(c->scratch, A + first * 5, sizeof(double) * 5 * cnt, hipMemcpyHostToDevice,
                                c->stream));
         hipLaunchKernelGGL(k_import_aos, dim3(grid_for(cnt)), dim3(256), 0, c->stream,
-                           (const double *)c->scratch, first, cnt, soa_of(c));
+                           (const double *)c->scratch, first, cnt, c->nx, c->nxt, soa_of(c));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    HIP_TRY(hipMemcpyAsync(c->b, b, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
+    TRY(rows_h2d(c, c->b, b, (size_t)c->rows));
+    if (c->nx != c->nxt) {
+        hipLaunchKernelGGL(k_pad_identity, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, c->nx, c->nxt,
+                           c->rows, soa_of(c));
+        HIP_TRY(hipGetLastError());
+    }
     c->CL = CL; c->CR = CR;
     c->have_walls = false;
     if (D) {
         TRY(ensure_walls(c));
         // only the first and last column of D are ever read (cuh:1256-1257)
         for (int i = 0; i < c->rows; ++i) {
-            c->mf_host[i] = D[(size_t)i * c->nx];
-            c->mf_host[c->rows + i] = D[(size_t)(i + 1) * c->nx - 1];
+            c->mf_host[i] = D[(size_t)i * c->nxt];
+            c->mf_host[c->rows + i] = D[(size_t)(i + 1) * c->nxt - 1];
         }
         HIP_TRY(hipMemcpyAsync(c->Dl, c->mf_host, sizeof(double) * c->rows, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->Dr, c->mf_host + c->rows, sizeof(double) * c->rows, hipMemcpyHostToDevice,
@@ -515,16 +527,17 @@ try {
     TRY(use_device(c));
     if (c->have_explicit) {
         TRY(ensure_scratch(c, sizeof(double) * 5 * CHUNK_CELLS));
-        for (size_t first = 0; first < c->n; first += CHUNK_CELLS) {
-            const size_t cnt = (c->n - first < CHUNK_CELLS) ? c->n - first : CHUNK_CELLS;
+        const size_t n_mesh = (size_t)c->nxt * c->rows;
+        for (size_t first = 0; first < n_mesh; first += CHUNK_CELLS) {
+            const size_t cnt = (n_mesh - first < CHUNK_CELLS) ? n_mesh - first : CHUNK_CELLS;
             hipLaunchKernelGGL(k_export_aos, dim3(grid_for(cnt)), dim3(256), 0, c->stream, (double *)c->scratch,
-                               first, cnt, soa_of(c));
+                               first, cnt, c->nx, c->nxt, soa_of(c));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(A + first * 5, c->scratch, sizeof(double) * 5 * cnt, hipMemcpyDeviceToHost,
                                    c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
         }
-        HIP_TRY(hipMemcpyAsync(b, c->b, sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
+        TRY(rows_d2h(c, b, c->b, (size_t)c->rows));
         HIP_TRY(hipStreamSynchronize(c->stream));
         return DEFF_OK;
     }
@@ -533,11 +546,13 @@ try {
         std::vector<uint16_t> code(c->n);
         HIP_TRY(hipMemcpyAsync(code.data(), c->code, sizeof(uint16_t) * c->n, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        for (size_t p = 0; p < c->n; ++p) {
-            const double *row = &c->lut_rows[(size_t)(code[p] >> 3) * 6];
-            for (int k = 0; k < 5; ++k) A[p * 5 + k] = row[k];
-            b[p] = row[5];
-        }
+        for (int i = 0; i < c->rows; ++i)
+            for (int j = 0; j < c->nxt; ++j) {
+                const size_t p = (size_t)i * c->nxt + j;
+                const double *row = &c->lut_rows[(size_t)(code[(size_t)i * c->nx + j] >> 3) * 6];
+                for (int k = 0; k < 5; ++k) A[p * 5 + k] = row[k];
+                b[p] = row[5];
+            }
         return DEFF_OK;
     }
     return fail(DEFF_ESTATE, "no system assembled");
@@ -551,7 +566,7 @@ try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     TRY(use_device(c));
     hipLaunchKernelGGL(k_init_linear, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->x[c->cur], c->nx,
-                       c->rows, CL, CR, c->fma);
+                       c->nxt, c->rows, CL, CR, c->fma);
     HIP_TRY(hipGetLastError());
     c->have_field = true;
     reset_batch_state(c);
@@ -580,7 +595,7 @@ extern "C" int deff_set_field(deff_ctx *c, const double *x)
 try {
     if (!c || !x) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
-    HIP_TRY(hipMemcpyAsync(c->x[c->cur], x, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
+    TRY(rows_h2d(c, c->x[c->cur], x, (size_t)c->rows));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_field = true;
     reset_batch_state(c);
@@ -593,7 +608,7 @@ try {
     if (!c || !x) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
     TRY(consolidate(c));
-    HIP_TRY(hipMemcpyAsync(x, c->x[c->cur], sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
+    TRY(rows_d2h(c, x, (const double *)c->x[c->cur], (size_t)c->rows));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DEFF_OK;
 }

@@ -673,7 +673,7 @@ static int rank_flux(deff_slab_rank *s, double *deff_raw)
     deff_ctx *c = s->ctx;
     if (!c->have_walls) return fail(DEFF_ESTATE, "wall diffusivities unknown");
     hipLaunchKernelGGL(k_wall_flux, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, c->x[c->cur], c->Dl, c->Dr,
-                       c->nx, c->rows, c->dx, c->CL, c->CR, c->mf);
+                       c->nx, c->nxt, c->rows, c->dx, c->CL, c->CR, c->mf);
     hipLaunchKernelGGL(k_pack_own_flux, dim3((c->own_h + 255) / 256), dim3(256), 0, c->stream, c->mf, c->rows, c->own_lo,
                        c->own_h, s->maxown, s->d_pack);
     HIP_TRY(hipGetLastError());

@@ -75,7 +75,7 @@ int default_tb_T(const deff_ctx *c)
 static int try_dict(deff_ctx *c)
 {
     c->dict_tried = true;
-    if (!c->have_explicit || (c->nx & 1)) return DEFF_OK;
+    if (!c->have_explicit) return DEFF_OK;
     const size_t S = DICT_SLOTS;
     const size_t bytes = S * (8 + 4 + 8) + 16 + S * 2 + (size_t)LUT_MAX_ROWS * (8 + 48);
     TRY(ensure_scratch(c, bytes));
@@ -121,7 +121,7 @@ static int try_dict(deff_ctx *c)
     const int nrows = (int)ents.size();
     hipLaunchKernelGGL(k_dict_gather, dim3((nrows + 255) / 256), dim3(256), 0, c->stream, planes, d_cells, nrows, d_rows);
     TRY(dev_alloc(&c->code, c->n));
-    hipLaunchKernelGGL(k_dict_encode, dim3(grid_for(c->n, 4096)), dim3(256), 0, c->stream, planes, c->n, c->nx, t,
+    hipLaunchKernelGGL(k_dict_encode, dim3(grid_for(c->n, 4096)), dim3(256), 0, c->stream, planes, c->n, c->nx, c->nxt, t,
                        d_slot2code, c->code);
     HIP_TRY(hipGetLastError());
     std::vector<double> rows((size_t)nrows * 6);
@@ -207,8 +207,7 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             // the reference's non-zero link test matters only when a phase cannot diffuse
             pl->guard = c->lut_guard;
         }
-        const int vec = (c->nx & 1) ? 1 : 2;
-        tile_grid(c, 256 * vec, pick_R(c->rows_matfree, c->n >= ((size_t)1 << 21) ? 8 : 2), pl);
+        tile_grid(c, 256 * 2, pick_R(c->rows_matfree, c->n >= ((size_t)1 << 21) ? 8 : 2), pl);
         // persistent grid: a few workgroups per CU walk the tiles (tables loaded once each)
         const int cap = c->wg_matfree ? c->wg_matfree : 256 * 8;
         if (pl->blocks > cap) pl->blocks = cap;
@@ -270,20 +269,11 @@ void enqueue_sweep(deff_ctx *c, const SweepPlan &pl)
                        c->lut_nrows, pl.omw)
 #define LAUNCH_MATFREE(V_, R_)                                                                               \
     do { if (pl.fma) LAUNCH_MATFREE_(V_, R_, true); else LAUNCH_MATFREE_(V_, R_, false); } while (0)
-        if (c->nx & 1) {
-            switch (pl.rows) {
-            case 1: LAUNCH_MATFREE(1, 1); break;
-            case 2: LAUNCH_MATFREE(1, 2); break;
-            case 4: LAUNCH_MATFREE(1, 4); break;
-            default: LAUNCH_MATFREE(1, 8); break;
-            }
-        } else {
-            switch (pl.rows) {
-            case 1: LAUNCH_MATFREE(2, 1); break;
-            case 2: LAUNCH_MATFREE(2, 2); break;
-            case 4: LAUNCH_MATFREE(2, 4); break;
-            default: LAUNCH_MATFREE(2, 8); break;
-            }
+        switch (pl.rows) {
+        case 1: LAUNCH_MATFREE(2, 1); break;
+        case 2: LAUNCH_MATFREE(2, 2); break;
+        case 4: LAUNCH_MATFREE(2, 4); break;
+        default: LAUNCH_MATFREE(2, 8); break;
         }
 #undef LAUNCH_MATFREE
 #undef LAUNCH_MATFREE_
@@ -303,7 +293,8 @@ void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl)
 #define LAUNCH_TB(T_, C_, G_)                                                                                  \
     hipLaunchKernelGGL((k_sweep_matfree_tb<T_, C_, G_>), dim3(pl.tblocks), dim3(256), 0, c->stream, c->lut,    \
                        c->code, xin, xout, c->nx, c->mesh_ny, c->ny, c->dom_lo, c->own_lo, c->own_h, pl.tcpi, \
-                       mask, pl.LY, pl.ntx, pl.tgx, pl.tgy, flip, c->tb_xmajor, c->lut_allb ? 1 : 0,         \
+                       mask, pl.LY, pl.ntx, pl.tgx, pl.tgy, flip, c->tb_xmajor,                              \
+                       (c->lut_allb || c->nx != c->nxt) ? 1 : 0, /* padded: the wall column may not be in the last strip */ \
                        c->lut_nrows, pl.shift, pl.omw, c->tb_stamps)
     TB_DISPATCH(pl.T, pl.fma, pl.guard, LAUNCH_TB);
 #undef LAUNCH_TB
@@ -345,7 +336,7 @@ int flux_rows(deff_ctx *c)
     if (!c->have_walls)
         return fail(DEFF_ESTATE, "wall diffusivities unknown: pass D to deff_set_system() or assemble on the device");
     hipLaunchKernelGGL(k_wall_flux, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, c->x[c->cur], c->Dl,
-                       c->Dr, c->nx, c->rows, c->dx, c->CL, c->CR, c->mf);
+                       c->Dr, c->nx, c->nxt, c->rows, c->dx, c->CL, c->CR, c->mf);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->mf_host, c->mf, sizeof(double) * 2 * c->rows, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -485,11 +476,11 @@ static int stream_load_slot(deff_ctx *c, int slot, const uint8_t *pix_host)
     HIP_TRY(hipMemcpyAsync(dpix, pix_host, npix, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));        // pix_host is the caller's scratch
     hipLaunchKernelGGL(k_phase_codes, dim3(grid_for(c->n_img)), dim3(256), 0, c->stream, dpix, c->W, c->ampX, c->ampY,
-                       c->nx, c->ny, c->ny, 0, c->ny, dcode);
+                       c->nx, c->nxt, c->ny, c->ny, 0, c->ny, dcode);
     hipLaunchKernelGGL(k_wall_D_2phase, dim3((c->ny + 255) / 256), dim3(256), 0, c->stream, dpix, c->W, c->ampX, c->ampY,
-                       c->nx, c->ny, c->ny, c->Df, c->Ds, c->Dl + (size_t)slot * c->ny, c->Dr + (size_t)slot * c->ny);
+                       c->nxt, c->ny, c->ny, c->Df, c->Ds, c->Dl + (size_t)slot * c->ny, c->Dr + (size_t)slot * c->ny);
     hipLaunchKernelGGL(k_init_linear, dim3(grid_for(c->n_img)), dim3(256), 0, c->stream,
-                       c->x[c->cur] + (size_t)slot * c->n_img, c->nx, c->ny, c->CL, c->CR, c->fma);
+                       c->x[c->cur] + (size_t)slot * c->n_img, c->nx, c->nxt, c->ny, c->CL, c->CR, c->fma);
     HIP_TRY(hipGetLastError());
     c->buf_of[slot] = (uint8_t)c->cur;
     return DEFF_OK;
@@ -512,8 +503,8 @@ extern "C" int deff_get_slot_field(deff_ctx *c, int slot, double *x)
 try {
     if (!c || !x || slot < 0 || slot >= c->nimg) return fail(DEFF_EINVAL, "bad slot");
     TRY(use_device(c));
-    HIP_TRY(hipMemcpyAsync(x, c->x[(c->masked || c->in_stream) ? c->buf_of[slot] : c->cur] + (size_t)slot * c->n_img,
-                           sizeof(double) * c->n_img, hipMemcpyDeviceToHost, c->stream));
+    TRY(rows_d2h(c, x, (const double *)(c->x[(c->masked || c->in_stream) ? c->buf_of[slot] : c->cur] + (size_t)slot * c->n_img),
+                 (size_t)c->ny));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DEFF_OK;
 }

@@ -58,6 +58,9 @@ struct deff_ctx {
     size_t n_img = 0;               // cells per image
     size_t n = 0;                   // cells in the stack
     double dx = 0, dy = 0;
+    // nx is the width of every device array (even); nxt <= nx the width of the mesh -- an odd mesh
+    // width is padded by one column of cells outside the mesh (kernels_setup.hpp, "Row pitch")
+    int nxt = 0;
     // Row slab of a taller image (multi-GPU split of one image): the arrays hold
     // `halo` rows above and below the `own_h` rows this context updates; array row li is mesh row
     // li - dom_lo of a mesh_ny-row mesh.  Plain contexts: dom_lo = 0, mesh_ny = own_h = ny, halo = 0.
@@ -174,6 +177,28 @@ static inline int grid_for(size_t n, int cap = 16384)
 {
     size_t g = (n + 255) / 256;
     return (int)(g < (size_t)cap ? (g ? g : 1) : (size_t)cap);
+}
+
+// rows of nxt elements on the host <-> rows of nx elements on the device
+template <typename T>
+static inline int rows_h2d(deff_ctx *c, T *dst, const T *src, size_t rows)
+{
+    if (c->nx == c->nxt)
+        HIP_TRY(hipMemcpyAsync(dst, src, sizeof(T) * c->nx * rows, hipMemcpyHostToDevice, c->stream));
+    else
+        HIP_TRY(hipMemcpy2DAsync(dst, sizeof(T) * c->nx, src, sizeof(T) * c->nxt, sizeof(T) * c->nxt, rows,
+                                 hipMemcpyHostToDevice, c->stream));
+    return DEFF_OK;
+}
+template <typename T>
+static inline int rows_d2h(deff_ctx *c, T *dst, const T *src, size_t rows)
+{
+    if (c->nx == c->nxt)
+        HIP_TRY(hipMemcpyAsync(dst, src, sizeof(T) * c->nx * rows, hipMemcpyDeviceToHost, c->stream));
+    else
+        HIP_TRY(hipMemcpy2DAsync(dst, sizeof(T) * c->nxt, src, sizeof(T) * c->nx, sizeof(T) * c->nxt, rows,
+                                 hipMemcpyDeviceToHost, c->stream));
+    return DEFF_OK;
 }
 
 static inline CoefSoA soa_of(deff_ctx *c) { return CoefSoA{c->a0, c->aW, c->aE, c->aS, c->aN, c->b}; }

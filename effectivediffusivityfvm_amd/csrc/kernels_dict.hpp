@@ -76,7 +76,7 @@ static __global__ void k_dict_insert(CoefSoA c, size_t n, DictTable t)
 }
 
 // slot2code[s] = code (row index x 8) of slot s, 0xFFFF when the slot got no row (too many rows)
-static __global__ void k_dict_encode(CoefSoA c, size_t n, int nx, DictTable t, const uint16_t *__restrict__ slot2code,
+static __global__ void k_dict_encode(CoefSoA c, size_t n, int nx, int nxt, DictTable t, const uint16_t *__restrict__ slot2code,
                               uint16_t *__restrict__ code)
 {
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
@@ -91,7 +91,7 @@ static __global__ void k_dict_encode(CoefSoA c, size_t n, int nx, DictTable t, c
                           __double_as_longlong(c.b[p]) == __double_as_longlong(c.b[q]);
         if (!same) t.flags[1] = 1;
         const int j = (int)(p % (size_t)nx);
-        if (j != 0 && j != nx - 1 && c.b[p] != 0) t.flags[2] = 1;
+        if (j != 0 && j != nxt - 1 && c.b[p] != 0) t.flags[2] = 1;
         code[p] = slot2code[s];
     }
 }

@@ -9,6 +9,12 @@
 // images, so the stack is swept as a single domain; only the position class of
 // a row (first / last / interior row OF ITS IMAGE) has to be taken modulo ny.
 // Below `rows` = nimg*ny is the stacked height and `ny` the height of one image.
+//
+// Row pitch: device arrays are `nx` wide, the mesh `nxt` <= nx: an odd mesh width is padded by
+// one column so that rows stay 16-byte aligned for the two-cells-per-lane kernels.  Pad cells are
+// outside the mesh: code 0 (the zero row) / an identity row in explicit planes, field 0, linked
+// to nothing (the last mesh column has no east link, the first none to the west), so they never
+// change and never contribute.  Geometry (wall columns, dx = 1/nxt, the linear guess) uses nxt.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -58,25 +64,26 @@ __device__ __forceinline__ uint8_t cell_pixel(const uint8_t *pix, int W, int amp
 
 // 2-phase D fill, cuh:1988-2000: pixel < 150 -> fluid.
 static __global__ void k_fill_D_2phase(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
-                                int nx, int ny, int rows, double DCF, double DCS, double *__restrict__ D)
+                                int nx, int nxt, int ny, int rows, double DCF, double DCS, double *__restrict__ D)
 {
     const size_t n = (size_t)nx * rows;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
          p += (size_t)gridDim.x * blockDim.x) {
         int i = (int)(p / nx), j = (int)(p % nx);
-        D[p] = (cell_pixel(pix, W, ampX, ampY, ny, i, j) < 150) ? DCF : DCS;
+        D[p] = j >= nxt ? 0.0 : ((cell_pixel(pix, W, ampX, ampY, ny, i, j) < 150) ? DCF : DCS);
     }
 }
 
 // 3-phase D fill, cuh:1518-1529: pixel > 200 -> solid, < 50 -> gas, otherwise fluid.
 static __global__ void k_fill_D_3phase(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
-                                int nx, int ny, int rows, double DCF, double DCS, double DCG,
+                                int nx, int nxt, int ny, int rows, double DCF, double DCS, double DCG,
                                 double *__restrict__ D)
 {
     const size_t n = (size_t)nx * rows;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
          p += (size_t)gridDim.x * blockDim.x) {
         int i = (int)(p / nx), j = (int)(p % nx);
+        if (j >= nxt) { D[p] = 0.0; continue; }
         const uint8_t v = cell_pixel(pix, W, ampX, ampY, ny, i, j);
         D[p] = (v > 200) ? DCS : (v < 50 ? DCG : DCF);
     }
@@ -85,22 +92,22 @@ static __global__ void k_fill_D_3phase(const uint8_t *__restrict__ pix, int W, i
 // Diffusivity of the first and last cell of every row, for the wall fluxes
 // (cuh:1256-1257 read D[j*nx] and D[(j+1)*nx-1]).
 static __global__ void k_wall_D_2phase(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
-                                int nx, int ny, int rows, double DCF, double DCS,
+                                int nxt, int ny, int rows, double DCF, double DCS,
                                 double *__restrict__ Dl, double *__restrict__ Dr)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
     Dl[i] = (cell_pixel(pix, W, ampX, ampY, ny, i, 0) < 150) ? DCF : DCS;
-    Dr[i] = (cell_pixel(pix, W, ampX, ampY, ny, i, nx - 1) < 150) ? DCF : DCS;
+    Dr[i] = (cell_pixel(pix, W, ampX, ampY, ny, i, nxt - 1) < 150) ? DCF : DCS;
 }
 
-static __global__ void k_wall_D_from_D(const double *__restrict__ D, int nx, int rows,
+static __global__ void k_wall_D_from_D(const double *__restrict__ D, int nx, int nxt, int rows,
                                 double *__restrict__ Dl, double *__restrict__ Dr)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
     Dl[i] = D[(size_t)i * nx];
-    Dr[i] = D[(size_t)(i + 1) * nx - 1];
+    Dr[i] = D[(size_t)i * nx + nxt - 1];
 }
 
 // Matrix-free code, 16 bits per cell: the BYTE OFFSET (row index x 8) of the cell's matrix
@@ -112,7 +119,7 @@ static __global__ void k_wall_D_from_D(const double *__restrict__ D, int nx, int
 // dom_lo / mesh_ny: array row li of an image is mesh row li - dom_lo of a mesh_ny-row mesh
 // (dom_lo = 0, mesh_ny = ny except for a row slab, whose array is a window with halo rows).
 static __global__ void k_phase_codes(const uint8_t *__restrict__ pix, int W, int ampX, int ampY,
-                              int nx, int ny, int rows, int dom_lo, int mesh_ny,
+                              int nx, int nxt, int ny, int rows, int dom_lo, int mesh_ny,
                               uint16_t *__restrict__ code)
 {
     const size_t n = (size_t)nx * rows;
@@ -121,8 +128,8 @@ static __global__ void k_phase_codes(const uint8_t *__restrict__ pix, int W, int
         int i = (int)(p / nx), j = (int)(p % nx);
         const int li = i % ny;                       // row inside its image's array
         const int gi = li - dom_lo;                  // mesh row
-        if (gi < 0 || gi >= mesh_ny) { code[p] = 0; continue; }
-        int jw = j > 0 ? j - 1 : j, je = j < nx - 1 ? j + 1 : j;
+        if (gi < 0 || gi >= mesh_ny || j >= nxt) { code[p] = 0; continue; }
+        int jw = j > 0 ? j - 1 : j, je = j < nxt - 1 ? j + 1 : j;
         int is = (gi < mesh_ny - 1 && li < ny - 1) ? i + 1 : i;
         int in = (gi > 0 && li > 0) ? i - 1 : i;
         unsigned c = (cell_pixel(pix, W, ampX, ampY, ny, i, j) >= 150) ? 1u : 0u;
@@ -130,7 +137,7 @@ static __global__ void k_phase_codes(const uint8_t *__restrict__ pix, int W, int
         c |= (cell_pixel(pix, W, ampX, ampY, ny, i, je) >= 150) ? 4u : 0u;
         c |= (cell_pixel(pix, W, ampX, ampY, ny, is, j) >= 150) ? 8u : 0u;
         c |= (cell_pixel(pix, W, ampX, ampY, ny, in, j) >= 150) ? 16u : 0u;
-        const unsigned cls = (unsigned)(pos_class(gi, mesh_ny) * 3 + pos_class(j, nx));
+        const unsigned cls = (unsigned)(pos_class(gi, mesh_ny) * 3 + pos_class(j, nxt));
         code[p] = (uint16_t)((1u + cls * 32u + c) * 8u);
     }
 }
@@ -145,7 +152,7 @@ struct CoefSoA {
 // with Grid != nullptr, DiscretizeMatrix2D_ImpSolid cuh:715-812: Grid 1 or 2
 // gets the identity row, cuh:750-752).
 static __global__ void k_assemble_from_D(const double *__restrict__ D, const unsigned int *__restrict__ Grid,
-                                  int nx, int ny, int rows, double dx, double dy, double CL, double CR,
+                                  int nx, int nxt, int ny, int rows, double dx, double dy, double CL, double CR,
                                   CoefSoA c)
 {
     const size_t n = (size_t)nx * rows;
@@ -153,39 +160,56 @@ static __global__ void k_assemble_from_D(const double *__restrict__ D, const uns
          p += (size_t)gridDim.x * blockDim.x) {
         int i = (int)(p / nx) % ny, j = (int)(p % nx);   // i: row inside its image
         FvmRow r;
-        if (Grid != nullptr && (Grid[p] == 1 || Grid[p] == 2)) {
+        if (j >= nxt || (Grid != nullptr && (Grid[p] == 1 || Grid[p] == 2))) {    // pad column: identity row too
             r.a0 = 1; r.aW = 0; r.aE = 0; r.aS = 0; r.aN = 0; r.b = 0;
         } else {
             // clamped neighbour reads; values at clamped positions are unused
             double Dp = D[p];
             double Dw = D[j > 0 ? p - 1 : p];
-            double De = D[j < nx - 1 ? p + 1 : p];
+            double De = D[j < nxt - 1 ? p + 1 : p];
             double Ds = D[i < ny - 1 ? p + nx : p];
             double Dn = D[i > 0 ? p - nx : p];
-            r = fvm_row(Dp, Dw, De, Ds, Dn, pos_class(j, nx), pos_class(i, ny), dx, dy, CL, CR);
+            r = fvm_row(Dp, Dw, De, Ds, Dn, pos_class(j, nxt), pos_class(i, ny), dx, dy, CL, CR);
         }
         c.a0[p] = r.a0; c.aW[p] = r.aW; c.aE[p] = r.aE; c.aS[p] = r.aS; c.aN[p] = r.aN; c.b[p] = r.b;
     }
 }
 
-// AoS [cells][5] chunk -> SoA planes (import of a host-assembled matrix).
-static __global__ void k_import_aos(const double *__restrict__ A, size_t first, size_t count, CoefSoA c)
+// AoS [cells][5] chunk -> SoA planes (import of a host-assembled matrix).  `first`, `count` count
+// mesh cells (rows of nxt); the planes are nx wide.
+__device__ __forceinline__ size_t padded_index(size_t cell, int nx, int nxt)
+{
+    return nx == nxt ? cell : (cell / (size_t)nxt) * (size_t)nx + cell % (size_t)nxt;
+}
+
+static __global__ void k_import_aos(const double *__restrict__ A, size_t first, size_t count, int nx, int nxt, CoefSoA c)
 {
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < count;
          q += (size_t)gridDim.x * blockDim.x) {
         const double *a = A + q * 5;
-        size_t p = first + q;
+        size_t p = padded_index(first + q, nx, nxt);
         c.a0[p] = a[0]; c.aW[p] = a[1]; c.aE[p] = a[2]; c.aS[p] = a[3]; c.aN[p] = a[4];
     }
 }
 
-static __global__ void k_export_aos(double *__restrict__ A, size_t first, size_t count, CoefSoA c)
+static __global__ void k_export_aos(double *__restrict__ A, size_t first, size_t count, int nx, int nxt, CoefSoA c)
 {
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < count;
          q += (size_t)gridDim.x * blockDim.x) {
         double *a = A + q * 5;
-        size_t p = first + q;
+        size_t p = padded_index(first + q, nx, nxt);
         a[0] = c.a0[p]; a[1] = c.aW[p]; a[2] = c.aE[p]; a[3] = c.aS[p]; a[4] = c.aN[p];
+    }
+}
+
+// identity rows in the pad column of explicit planes (imported systems)
+static __global__ void k_pad_identity(int nx, int nxt, int rows, CoefSoA c)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    for (int j = nxt; j < nx; ++j) {
+        const size_t p = (size_t)i * nx + j;
+        c.a0[p] = 1; c.aW[p] = 0; c.aE[p] = 0; c.aS[p] = 0; c.aN[p] = 0; c.b[p] = 0;
     }
 }
 
@@ -203,13 +227,14 @@ static __global__ void k_make_c0(const double *__restrict__ a0, double w, double
 
 // Linear ramp, cuh:1955-1959: (double)j/nx*(CR-CL)+CL; `contracted` = the product fused into the
 // add, as in the contracted build of the reference's expression (see kernels_sweep.hpp, FMA).
-static __global__ void k_init_linear(double *__restrict__ x, int nx, int rows, double CL, double CR, int contracted)
+static __global__ void k_init_linear(double *__restrict__ x, int nx, int nxt, int rows, double CL, double CR, int contracted)
 {
     const size_t n = (size_t)nx * rows;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
          p += (size_t)gridDim.x * blockDim.x) {
         int j = (int)(p % nx);
-        x[p] = contracted ? __builtin_fma((double)j / nx, (CR - CL), CL) : (double)j / nx * (CR - CL) + CL;
+        if (j >= nxt) { x[p] = 0.0; continue; }
+        x[p] = contracted ? __builtin_fma((double)j / nxt, (CR - CL), CL) : (double)j / nxt * (CR - CL) + CL;
     }
 }
 
@@ -217,13 +242,13 @@ static __global__ void k_init_linear(double *__restrict__ x, int nx, int rows, d
 // (cuh:1258-1259) so Deff has the reference's summation order; the transfer is
 // 16*ny bytes per check instead of the reference's whole field (cuh:1245).
 static __global__ void k_wall_flux(const double *__restrict__ x, const double *__restrict__ Dl,
-                            const double *__restrict__ Dr, int nx, int rows, double dx,
+                            const double *__restrict__ Dr, int nx, int nxt, int rows, double dx,
                             double CL, double CR, double *__restrict__ mf)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
     mf[i] = Dl[i] * (x[(size_t)i * nx] - CL) / (dx / 2.0);
-    mf[rows + i] = Dr[i] * (CR - x[(size_t)(i + 1) * nx - 1]) / (dx / 2.0);
+    mf[rows + i] = Dr[i] * (CR - x[(size_t)i * nx + nxt - 1]) / (dx / 2.0);
 }
 
 }  // namespace deff

@@ -21,7 +21,7 @@
 // never dereferenced (the reference relies on the zero coefficient there).
 //
 // Kernels:
-//   k_sweep_scalar    1 cell / thread, SoA coefficients, any nx
+//   k_sweep_scalar    1 cell / thread, SoA coefficients (the simplest form; kept selectable as a cross-check)
 //   k_sweep_explicit  2 x R cells / thread (16-B accesses), SoA coefficient
 //                     streams, all loads of a register tile issued up front:
 //                     64 B/cell/sweep of HBM
@@ -223,7 +223,8 @@ __device__ __forceinline__ void tile_coords(unsigned t, int gy, int &bx, int &by
     by = (int)(t % (unsigned)gy);
 }
 
-// VEC = 2 needs nx even; VEC = 1 handles any nx.  Tile = 256*VEC columns x R
+// VEC = 2 (the form in use: array rows are always even, an odd mesh width is padded); VEC = 1 is the
+// one-cell-per-thread form, no longer instantiated.  Tile = 256*VEC columns x R
 // rows.  Position classes are folded into the codes at assembly, the kernel only looks rows up.  Persistent: the grid is a few workgroups per CU, each loads the tables
 // into LDS once and then walks its share of the tiles.
 template <int VEC, int R, bool FMA>

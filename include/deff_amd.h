@@ -215,8 +215,9 @@ int deff_slab_rank_solve(deff_slab_rank *s, double omega, double tol, int64_t ma
 /* diagnostics: wall-clock (100 MHz) start/end of every wave tile of one temporally blocked pass */
 int deff_debug_tb_stamps(deff_ctx *ctx, double omega, unsigned long long *out, int *ntiles);
 
-/* raw device pointers for zero-copy interop (torch tensors, RCCL): current field,
- * and the byte pitch between rows (nx*8: rows are dense) */
+/* raw device pointers for zero-copy interop (torch tensors, RCCL): current field, and the byte
+ * pitch between rows -- nx*8 for an even nx, (nx+1)*8 for an odd one (device rows are padded to an
+ * even number of cells; the pad cell holds 0 and is not part of the mesh) */
 int deff_device_field(deff_ctx *ctx, void **d_x, size_t *row_pitch_bytes);
 int deff_synchronize(deff_ctx *ctx);
 

@@ -540,6 +540,86 @@ def test_slab_ranks_three_processes_one_gpu(pkg, oracle, tmp_path):
         assert np.array_equal(np.load(tmp_path / f"mfl{k}.npy"), MFL)
 
 
+# ---- odd mesh widths: arrays padded to an even pitch, every fast kernel available ---------------
+
+@pytest.mark.parametrize("nx,ny", [(97, 41), (1001, 333), (3, 5), (129, 64)])
+def test_odd_width_runs_on_the_blocked_kernel(pkg, oracle, nx, ny):
+    """An odd nx is padded by one column of cells outside the mesh; geometry (dx, wall column, linear
+    guess) stays that of the true width.  Full solve, fluxes, field, system export."""
+    rng = np.random.default_rng(nx + ny)
+    pix = rand_mask(rng, nx, ny, 0.55)
+    CL, CR = 0.2, 1.1
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-2)
+    A, b = oracle.discretize(D, CL, CR)
+    x0 = oracle.linear_guess(nx, ny, CL, CR)
+    it, deff, conv, x, MFL, MFR = oracle.jacobi(A, b, x0, D, CL, CR, 1e-4, 3000, check_every=100)
+    with pkg.Solver(nx, ny) as s:
+        s.set_image(pix)
+        s.assemble_2phase(1e-2, 1.0, CL, CR)
+        A2, b2 = s.get_system()
+        assert np.array_equal(A2, A) and np.array_equal(b2, b)
+        s.init_linear(CL, CR)
+        assert np.array_equal(s.get_field(), x0)
+        r = s.solve(1e-4, 3000, check_every=100)
+        assert s.kernel_in_use() == ("matfree_tb" if ny >= 8 else "matfree")
+        assert (r.iters, r.deff_raw, r.conv) == (it, deff, conv)
+        assert np.array_equal(r.MFL, MFL) and np.array_equal(r.MFR, MFR)
+        assert_field(s.get_field(), x)
+    # the reference's own arrays in (drop-in route), explicit kernel and harvested dictionary
+    for kernel in ("explicit", "auto"):
+        with pkg.Solver(nx, ny, kernel=kernel) as s:
+            s.set_system(A, b, D, CL, CR)
+            A3, b3 = s.get_system()
+            assert np.array_equal(A3, A) and np.array_equal(b3, b)
+            s.set_field(x0)
+            r = s.solve(1e-4, 3000, check_every=100)
+            assert (r.iters, r.deff_raw, r.conv) == (it, deff, conv)
+            assert_field(s.get_field(), x)
+
+
+def test_odd_width_three_phase_batch_and_stream(pkg, oracle):
+    nx, ny = 75, 40
+    rng = np.random.default_rng(9)
+    # 3-phase with Grid through assemble_3phase and assemble_from_D
+    pix = rng.choice(np.array([0, 120, 255], dtype=np.uint8), size=(ny, nx), p=[0.3, 0.4, 0.3])
+    D = oracle.fill_D_3phase(pix, 1.0, 0.0, 50.0)
+    grid = (pix > 200).astype(np.uint32)
+    A, b = oracle.discretize(D, 0.0, 1.0, grid=grid)
+    ref = oracle.sweeps(A, b, oracle.linear_guess(nx, ny, 0.0, 1.0), 23)
+    with pkg.Solver(nx, ny) as s:
+        s.set_image(pix)
+        s.assemble_3phase(0.0, 1.0, 50.0, 0.0, 1.0, grid=grid)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(23)
+        assert_field(s.get_field(), ref)
+        s.assemble_from_D(D, 0.0, 1.0, grid=grid)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(23)
+        assert_field(s.get_field(), ref)
+    # a stack of 5 odd-width images: every image equal to its one-image run
+    imgs = [rand_mask(rng, nx, ny, 0.5) for _ in range(5)]
+    want = []
+    for im in imgs:
+        Dk = oracle.fill_D_2phase(im, 1.0, 1e-2)
+        Ak, bk = oracle.discretize(Dk, 0.0, 1.0)
+        want.append(oracle.jacobi(Ak, bk, oracle.linear_guess(nx, ny, 0.0, 1.0), Dk, 0.0, 1.0, 1e-3, 2000, check_every=100))
+    with pkg.Solver(nx, ny, nimg=5) as s:
+        s.set_image(np.concatenate(imgs))
+        s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        res = s.solve(1e-3, 2000, check_every=100)
+        x = s.get_field()
+        for k, (it, deff, conv, xk, _, _) in enumerate(want):
+            assert (res[k].iters, res[k].deff_raw, res[k].conv) == (it, deff, conv)
+            assert_field(x[k * ny:(k + 1) * ny], xk)
+    with pkg.Solver(nx, ny, nimg=2) as s:
+        got = s.solve_stream(imgs, 1e-2, 1.0, 0.0, 1.0, 1e-3, 2000, check_every=100, want_fields=True)
+        for k, (it, deff, conv, xk, _, _) in enumerate(want):
+            r = got[k]
+            assert (r.iters, r.deff_raw, r.conv) == (it, deff, conv)
+            assert_field(r.field, xk)
+
+
 # ---- contracted arithmetic (opt-in): the oracle's "fma" build is the checker ------------------
 
 @pytest.mark.parametrize("kernel,nx,ny", [("explicit", 96, 64), ("scalar", 97, 41), ("matfree", 96, 64),
