@@ -254,8 +254,10 @@ def main():
             # written per cell per LAUNCH (a temporally blocked launch does sweeps_per_launch sweeps on it)
             own = 18.0 * cells
             if kernel_used == "matfree_tb":
-                out["roofline"]["limiter"] = ("not HBM: FP64 VALU issue ~55 % + LDS row lookups ~43 % busy, "
-                                              "profiles/r01d_tb_sq_counters.json")
+                out["roofline"]["limiter"] = ("not HBM: FP64 issue ~50-55 % busy (an FP64 instruction issues once per "
+                                              "8 clocks from one wave, the 4-clock rate needs two ready waves per SIMD; "
+                                              "3-4 fit the registers), LDS row lookups ~40 %; profiles/r01d_tb_sq_counters.json, "
+                                              "tools/ubench")
             out["roofline"]["own_model"] = {
                 "bytes_per_launch": own,
                 "achieved": own / launch_s / 1e9,
