@@ -13,6 +13,7 @@
 // --arith contracted: products fused into adds the way a compiler contracts the reference's expressions
 // (kernels_sweep.hpp); default is the reference's written operation order.
 //
+// --devices with RunBatch 0 and two phases: the one image is split into row slabs over the listed GPUs.
 // --devices: batch mode over several GPUs from one process -- one host thread and one solver context
 // per listed device, images handed out from a shared counter, no inter-GPU communication.
 //
@@ -125,26 +126,74 @@ static void progress(int64_t iter, double deff, double change, void *user)
     std::printf("Iteration = %d, Deff = %1.3e, Deff Change = %1.3e\n", (int)iter, deff / *(double *)user, change);   // cuh:1270
 }
 
+// Where a 2-phase image is solved: one context on one GPU, or -- a single image with --devices
+// a,b,... -- row slabs over several GPUs (deff_slab_group_*, one exchange of 8 halo rows per
+// temporally blocked pass; results identical to the one-GPU run).
+struct OneGpu {
+    Session &S;
+    bool open(const Image &im, const Options &o, int nx, int ny)
+    {
+        if (!S.prepare(nx, ny)) return false;
+        CK(deff_set_image(S.ctx, im.pix.data(), im.W, im.H, o.MeshIncreaseX, o.MeshIncreaseY));
+        CK(deff_init_linear(S.ctx, o.CLeft, o.CRight));
+        return true;
+    }
+    bool assemble(const Options &o, double DCF) { CK(deff_assemble_2phase(S.ctx, o.DCsolid, DCF, o.CLeft, o.CRight)); return true; }
+    bool solve(const Options &o, double *scale, deff_result *r)
+    {
+        if (o.verbose == 1 && !o.BatchFlag) deff_set_progress(S.ctx, progress, scale);
+        const int rc = deff_solve(S.ctx, 2.0 / 3.0, o.ConvergeCriteria, o.MAX_ITER, 10000, r, nullptr, nullptr);
+        deff_set_progress(S.ctx, nullptr, nullptr);
+        CK(rc);
+        return true;
+    }
+    bool get_field(double *x) { CK(deff_get_field(S.ctx, x)); return true; }
+};
+
+struct Slabs {
+    const std::vector<int> &devices;
+    deff_slab_group *g = nullptr;
+    ~Slabs() { deff_slab_group_destroy(g); }
+    bool open(const Image &im, const Options &o, int nx, int ny)
+    {
+        if (nx & 1) { std::fprintf(stderr, "deff2d: row slabs over several GPUs need an even mesh width (got %d)\n", nx); return false; }
+        CK(deff_slab_group_create((int)devices.size(), devices.data(), nx, ny, &g));
+        CK(deff_slab_group_set_tuning(g, "fma", g_contracted));
+        std::vector<uint8_t> mesh_pix((size_t)nx * ny);              // the slabs take the image at mesh resolution
+        for (int i = 0; i < ny; ++i)
+            for (int j = 0; j < nx; ++j)
+                mesh_pix[(size_t)i * nx + j] = im.pix[(size_t)(i / o.MeshIncreaseY) * im.W + j / o.MeshIncreaseX];
+        CK(deff_slab_group_set_image(g, mesh_pix.data()));
+        CK(deff_slab_group_init_linear(g, o.CLeft, o.CRight));
+        if (o.verbose == 1) std::printf("Row slabs over %zu GPUs\n", devices.size());
+        return true;
+    }
+    bool assemble(const Options &o, double DCF) { CK(deff_slab_group_assemble_2phase(g, o.DCsolid, DCF, o.CLeft, o.CRight)); return true; }
+    bool solve(const Options &o, double *, deff_result *r)
+    {
+        CK(deff_slab_group_solve(g, 2.0 / 3.0, o.ConvergeCriteria, o.MAX_ITER, 10000, r, nullptr, nullptr));
+        return true;
+    }
+    bool get_field(double *x) { CK(deff_slab_group_get_field(g, x)); return true; }
+};
+
 // 2-phase image.  single = SingleSim's DCF ramp 100, 1e4, ... up to Df (cuh:1759-1817);
 // batch = BatchSim: one solve with Df (cuh:1939-2017).
-static bool solve_2phase(Session &S, const Image &im, const Options &o, bool single, Row *row, std::vector<double> *field)
+template <class Target>
+static bool solve_2phase(Target &&T, const Image &im, const Options &o, bool single, Row *row, std::vector<double> *field)
 {
     const int nx = im.W * o.MeshIncreaseX, ny = im.H * o.MeshIncreaseY;
-    if (!S.prepare(nx, ny)) return false;
     row->nElements = nx * ny;
     row->porosity = porosity_of(im);
     std::vector<unsigned int> grid = grid_of(im, o, 150);
     CK(deff_flood_fill(grid.data(), nx, ny, &row->path));
-    CK(deff_set_image(S.ctx, im.pix.data(), im.W, im.H, o.MeshIncreaseX, o.MeshIncreaseY));
-    CK(deff_init_linear(S.ctx, o.CLeft, o.CRight));
+    if (!T.open(im, o, nx, ny)) return false;
     double ms_total = 0;
     auto stage = [&](double DCF) -> bool {
-        CK(deff_assemble_2phase(S.ctx, o.DCsolid, DCF, o.CLeft, o.CRight));
+        if (!T.assemble(o, DCF)) return false;
         deff_result r;
         double scale = DCF;
-        if (o.verbose == 1 && !o.BatchFlag) deff_set_progress(S.ctx, progress, &scale);
-        CK(deff_solve(S.ctx, 2.0 / 3.0, o.ConvergeCriteria, o.MAX_ITER, 10000, &r, nullptr, nullptr));
-        deff_set_progress(S.ctx, nullptr, nullptr);
+        if (!T.solve(o, &scale, &r)) return false;
         if (o.verbose == 1) std::printf("Iterations taken = %ld\n", (long)r.iters);
         row->deff = r.deff_raw / DCF;                                 // cuh:1802 / cuh:2017
         row->conv = r.conv;
@@ -177,7 +226,7 @@ static bool solve_2phase(Session &S, const Image &im, const Options &o, bool sin
         if (!stage(o.DCfluid)) return false;
     }
     row->seconds = ms_total / 1000.0;
-    if (field) { field->resize((size_t)nx * ny); CK(deff_get_field(S.ctx, field->data())); }
+    if (field) { field->resize((size_t)nx * ny); if (!T.get_field(field->data())) return false; }
     return true;
 }
 
@@ -648,8 +697,10 @@ int main(int argc, char **argv)
             rows[(size_t)k] = Row();
             rows[(size_t)k].name = image_name(k);
             std::vector<double> field;
-            const bool ok = (o.nPhase == 2) ? solve_2phase(S, im, o, !o.BatchFlag, &rows[(size_t)k], want_field ? &field : nullptr)
-                                            : solve_3phase(S, im, o, &rows[(size_t)k], want_field ? &field : nullptr);
+            const bool slabs = o.nPhase == 2 && !o.BatchFlag && devices.size() >= 2;   // one image over several GPUs
+            const bool ok = slabs ? solve_2phase(Slabs{devices}, im, o, true, &rows[(size_t)k], want_field ? &field : nullptr)
+                            : (o.nPhase == 2) ? solve_2phase(OneGpu{S}, im, o, !o.BatchFlag, &rows[(size_t)k], want_field ? &field : nullptr)
+                                              : solve_3phase(S, im, o, &rows[(size_t)k], want_field ? &field : nullptr);
             if (!ok) { failed = true; return; }
             if (o.verbose == 1 && o.nPhase == 2) std::printf("Porosity = %g\n", rows[(size_t)k].porosity);
             progress_append(progress_path, k, rows[(size_t)k]);

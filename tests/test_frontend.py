@@ -155,6 +155,30 @@ def test_driver_2phase_batch_config1(built, tmp_path, recorded):
 
 
 @pytest.mark.gpu
+def test_driver_single_image_over_row_slabs(built, tmp_path, recorded):
+    """RunBatch 0 with --devices a,b,c: the one image is solved as three row slabs (here all on GPU 0);
+    iterations, Deff, conv and the field are those of the one-GPU run."""
+    shutil.copy(os.path.join(GOLDEN, "00000.jpg"), tmp_path / "00000.jpg")
+    _write_input(tmp_path / "input.txt", Phases=2, Ds="1e-3", Df=1, MeshAmpX=1, MeshAmpY=1, InputName="00000.jpg", CR=1,
+                 CL=0, OutputName="out.csv", printCMap=0, Convergence="1e-6", MaxIter="5e5", Verbose=1, RunBatch=0,
+                 NumImages=1)
+    outs = {}
+    for tag, extra in (("one", []), ("slabs", ["--devices", "0,0,0"])):
+        r = subprocess.run([EXE, "input.txt", "--json", f"{tag}.json", "--field-bin", tag] + extra, cwd=tmp_path,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        outs[tag] = (json.load(open(tmp_path / f"{tag}.json"))["results"][0],
+                     np.fromfile(tmp_path / f"{tag}_00000_128x128.f64"), r.stdout)
+    assert "Row slabs over 3 GPUs" in outs["slabs"][2]
+    rec = recorded["img00000_2phase_batch"]
+    for tag in outs:
+        res = outs[tag][0]
+        assert res["iterations"] == rec["iters"] and res["Deff"] == rec["deff_build_b"]
+    assert outs["one"][0]["converge"] == outs["slabs"][0]["converge"]
+    assert np.array_equal(outs["one"][1], outs["slabs"][1])
+
+
+@pytest.mark.gpu
 def test_driver_3phase_as_shipped(built, tmp_path, recorded):
     """The reference's shipped input.txt, pointed at 00000.jpg: 3 phases, DCG continuation."""
     shutil.copy(os.path.join(GOLDEN, "00000.jpg"), tmp_path / "00000.jpg")
