@@ -264,8 +264,8 @@ try {
     TRY(use_device(c));
     TRY(image_shape(c, c->nxt, c->ny, 1, 1));
     // stacked rows continue the per-pixel key, so a batch holds images img, img+1, ...
-    hipLaunchKernelGGL(k_synth_mask, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->nxt, c->rows,
-                       seed, img);
+    hipLaunchKernelGGL(k_synth_mask, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->nxt, c->ny,
+                       c->rows, seed, img);
     HIP_TRY(hipGetLastError());
     c->have_image = true;
     c->have_matfree = false;

@@ -33,10 +33,12 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
     return z ^ (z >> 31);
 }
 
-static __global__ void k_synth_mask(uint8_t *__restrict__ pix, int nx, int ny, uint64_t seed, uint64_t img)
+// `ny` rows per image, `rows` >= ny stacked rows: the stack holds images img, img+1, ... (the key of
+// a pixel is img*nx*ny + its index inside the image, and the stack just keeps counting).
+static __global__ void k_synth_mask(uint8_t *__restrict__ pix, int nx, int ny, int rows, uint64_t seed, uint64_t img)
 {
-    const size_t n = (size_t)nx * ny;
-    const uint64_t base = seed * 0x100000001B3ull + img * (uint64_t)n;
+    const size_t n = (size_t)nx * rows;
+    const uint64_t base = seed * 0x100000001B3ull + img * ((uint64_t)nx * (uint64_t)ny);
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
          p += (size_t)gridDim.x * blockDim.x)
         pix[p] = (splitmix64(base + p) >> 63) ? 255 : 0;

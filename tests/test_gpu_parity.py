@@ -99,6 +99,16 @@ def test_synth_generator_matches_oracle(pkg, oracle):
             assert np.array_equal(s.get_image(), oracle.synth_mask(nx, ny, 12345, img))
 
 
+def test_synthetic_stack_holds_consecutive_images(pkg, oracle):
+    """synth_image(seed, img) on a stack of B images = images img .. img+B-1 of the sequence."""
+    nx, ny, B = 70, 48, 3
+    with pkg.Solver(nx, ny, nimg=B) as s:
+        s.synth_image(12345, 5)
+        got = s.get_image()
+        for k in range(B):
+            assert np.array_equal(got[k * ny:(k + 1) * ny], oracle.synth_mask(nx, ny, 12345, 5 + k))
+
+
 # -------------------------------------------------------------------- sweeps
 
 @pytest.mark.parametrize("kernel", KERNELS)
