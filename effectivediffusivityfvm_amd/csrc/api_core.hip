@@ -78,6 +78,7 @@ try {
 
     deff_ctx *c = new (std::nothrow) deff_ctx();
     if (!c) return fail(DEFF_ENOMEM, "host allocation failed");
+    struct Guard { deff_ctx *c; ~Guard() { if (c) deff_destroy(c); } } guard{c};   // until handed to the caller
     c->device = device;
     c->nxt = nx;
     c->nx = (nx + 1) & ~1;          // arrays are padded to an even width (16-byte rows)
@@ -105,7 +106,8 @@ try {
             break;
         }
     } while (0);
-    if (rc != DEFF_OK) { deff_destroy(c); return rc; }
+    if (rc != DEFF_OK) return rc;
+    guard.c = nullptr;
     *out = c;
     return DEFF_OK;
 }

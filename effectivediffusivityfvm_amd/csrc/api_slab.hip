@@ -24,7 +24,7 @@ static const int SLAB_HALO = 8;
 extern "C" int deff_slab_group_destroy(deff_slab_group *g);
 
 struct deff_slab_group {
-    int n = 0, nx = 0, NY = 0;
+    int n = 0, nx = 0, nxt = 0, NY = 0;       // nx: width of the device rows (even), nxt: width of the image
     std::vector<deff_ctx *> ctx;
     std::vector<int> g0, own;                 // first global row and row count of every slab
     std::vector<hipEvent_t> done;             // "pass finished" per slab
@@ -51,11 +51,11 @@ extern "C" int deff_slab_group_create(int nslabs, const int *devices, int nx, in
 try {
     if (!out || nslabs < 1) return fail(DEFF_EINVAL, "bad slab group arguments");
     *out = nullptr;
-    if (nx < 2 || (nx & 1)) return fail(DEFF_EINVAL, "row-slab mode needs an even nx >= 2 (got %d)", nx);
+    if (nx < 2) return fail(DEFF_EINVAL, "row-slab mode needs nx >= 2 (got %d)", nx);
     if (NY / nslabs < SLAB_HALO) return fail(DEFF_EINVAL, "%d rows over %d slabs: fewer than %d rows per slab", NY, nslabs, SLAB_HALO);
     deff_slab_group *g = new (std::nothrow) deff_slab_group();
     if (!g) return fail(DEFF_ENOMEM, "host allocation failed");
-    g->n = nslabs; g->nx = nx; g->NY = NY;
+    g->n = nslabs; g->nxt = nx; g->nx = (nx + 1) & ~1; g->NY = NY;
     g->mfl.assign(NY, 0.0); g->mfr.assign(NY, 0.0);
     int rc = DEFF_OK;
     for (int r = 0; r < nslabs && rc == DEFF_OK; ++r) {
@@ -127,11 +127,11 @@ try {
     for (int r = 0; r < g->n; ++r) {
         deff_ctx *c = g->ctx[r];
         TRY(use_device(c));
-        TRY(image_shape(c, c->nx, c->ny, 1, 1));
-        HIP_TRY(hipMemsetAsync(c->pix, 0, c->n, c->stream));
+        TRY(image_shape(c, c->nxt, c->ny, 1, 1));
+        HIP_TRY(hipMemsetAsync(c->pix, 0, (size_t)c->nxt * c->rows, c->stream));
         int m0, a0, cnt;
         slab_window(g, r, &m0, &a0, &cnt);
-        HIP_TRY(hipMemcpyAsync(c->pix + (size_t)a0 * c->nx, pix + (size_t)m0 * c->nx, (size_t)cnt * c->nx,
+        HIP_TRY(hipMemcpyAsync(c->pix + (size_t)a0 * c->nxt, pix + (size_t)m0 * c->nxt, (size_t)cnt * c->nxt,
                                hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->have_image = true; c->have_matfree = false;
@@ -146,14 +146,14 @@ try {
     for (int r = 0; r < g->n; ++r) {
         deff_ctx *c = g->ctx[r];
         TRY(use_device(c));
-        TRY(image_shape(c, c->nx, c->ny, 1, 1));
-        HIP_TRY(hipMemsetAsync(c->pix, 0, c->n, c->stream));
+        TRY(image_shape(c, c->nxt, c->ny, 1, 1));
+        HIP_TRY(hipMemsetAsync(c->pix, 0, (size_t)c->nxt * c->rows, c->stream));
         int m0, a0, cnt;
         slab_window(g, r, &m0, &a0, &cnt);
         // the generator's key is seed*K + img*NY*nx + global cell index: start it at mesh row m0
-        const uint64_t base_img_cells = img * (uint64_t)g->NY * (uint64_t)g->nx + (uint64_t)m0 * (uint64_t)g->nx;
-        hipLaunchKernelGGL(k_synth_mask_at, dim3(grid_for((size_t)cnt * c->nx)), dim3(256), 0, c->stream,
-                           c->pix + (size_t)a0 * c->nx, (size_t)cnt * c->nx, seed, base_img_cells);
+        const uint64_t base_img_cells = img * (uint64_t)g->NY * (uint64_t)g->nxt + (uint64_t)m0 * (uint64_t)g->nxt;
+        hipLaunchKernelGGL(k_synth_mask_at, dim3(grid_for((size_t)cnt * c->nxt)), dim3(256), 0, c->stream,
+                           c->pix + (size_t)a0 * c->nxt, (size_t)cnt * c->nxt, seed, base_img_cells);
         HIP_TRY(hipGetLastError());
         c->have_image = true; c->have_matfree = false;
     }
@@ -186,8 +186,7 @@ try {
         HIP_TRY(hipMemsetAsync(c->x[c->cur], 0, sizeof(double) * c->n, c->stream));
         int m0, a0, cnt;
         slab_window(g, r, &m0, &a0, &cnt);
-        HIP_TRY(hipMemcpyAsync(c->x[c->cur] + (size_t)a0 * c->nx, x + (size_t)m0 * c->nx,
-                               sizeof(double) * (size_t)cnt * c->nx, hipMemcpyHostToDevice, c->stream));
+        TRY(rows_h2d(c, c->x[c->cur] + (size_t)a0 * c->nx, x + (size_t)m0 * c->nxt, (size_t)cnt));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->have_field = true;
         reset_batch_state(c);
@@ -202,8 +201,8 @@ try {
     for (int r = 0; r < g->n; ++r) {
         deff_ctx *c = g->ctx[r];
         TRY(use_device(c));
-        HIP_TRY(hipMemcpyAsync(x + (size_t)g->g0[r] * c->nx, c->x[c->cur] + (size_t)c->own_lo * c->nx,
-                               sizeof(double) * (size_t)g->own[r] * c->nx, hipMemcpyDeviceToHost, c->stream));
+        TRY(rows_d2h(c, x + (size_t)g->g0[r] * c->nxt, (const double *)(c->x[c->cur] + (size_t)c->own_lo * c->nx),
+                     (size_t)g->own[r]));
     }
     for (int r = 0; r < g->n; ++r) { TRY(use_device(g->ctx[r])); HIP_TRY(hipStreamSynchronize(g->ctx[r]->stream)); }
     return DEFF_OK;
@@ -389,7 +388,7 @@ DEFF_API_CATCH
 struct deff_slab_rank {
     deff_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;
-    int rank = 0, nranks = 1, nx = 0, NY = 0, maxown = 0;
+    int rank = 0, nranks = 1, nx = 0, nxt = 0, NY = 0, maxown = 0;   // nx: device row width (even), nxt: image width
     std::vector<int> g0, own;
     double *d_pack = nullptr, *d_all = nullptr;      // [2*maxown], [nranks*2*maxown]
     std::vector<double> h_all, mfl, mfr;
@@ -463,11 +462,11 @@ static int slab_rank_create_impl(int device, int nx, int NY, int rank, int nrank
 {
     if (!out || nranks < 1 || rank < 0 || rank >= nranks) return fail(DEFF_EINVAL, "bad slab rank arguments");
     *out = nullptr;
-    if (nx < 2 || (nx & 1)) return fail(DEFF_EINVAL, "row-slab mode needs an even nx >= 2 (got %d)", nx);
+    if (nx < 2) return fail(DEFF_EINVAL, "row-slab mode needs nx >= 2 (got %d)", nx);
     if (NY / nranks < SLAB_HALO) return fail(DEFF_EINVAL, "%d rows over %d ranks: fewer than %d rows per slab", NY, nranks, SLAB_HALO);
     deff_slab_rank *s = new (std::nothrow) deff_slab_rank();
     if (!s) return fail(DEFF_ENOMEM, "host allocation failed");
-    s->rank = rank; s->nranks = nranks; s->nx = nx; s->NY = NY;
+    s->rank = rank; s->nranks = nranks; s->nxt = nx; s->nx = (nx + 1) & ~1; s->NY = NY;
     for (int r = 0; r < nranks; ++r) {
         const int a = (int)((long long)NY * r / nranks), b = (int)((long long)NY * (r + 1) / nranks);
         s->g0.push_back(a); s->own.push_back(b - a);
@@ -476,7 +475,7 @@ static int slab_rank_create_impl(int device, int nx, int NY, int rank, int nrank
     s->mfl.assign(NY, 0.0); s->mfr.assign(NY, 0.0);
     s->h_all.assign((size_t)nranks * 2 * s->maxown, 0.0);
     s->xchg = xchg; s->gather = gather; s->user = user;
-    const size_t blk = (size_t)SLAB_HALO * nx;
+    const size_t blk = (size_t)SLAB_HALO * s->nx;
     if (xchg) {
         s->h_send_up.assign(blk, 0.0); s->h_send_dn.assign(blk, 0.0);
         s->h_recv_up.assign(blk, 0.0); s->h_recv_dn.assign(blk, 0.0);
@@ -540,11 +539,11 @@ try {
     if (!s || !pix_window) return fail(DEFF_EINVAL, "NULL argument");
     deff_ctx *c = s->ctx;
     TRY(use_device(c));
-    TRY(image_shape(c, c->nx, c->ny, 1, 1));
+    TRY(image_shape(c, c->nxt, c->ny, 1, 1));
     int a = 0, cnt = 0;
     TRY(deff_slab_rank_window(s, &a, &cnt));
-    HIP_TRY(hipMemsetAsync(c->pix, 0, c->n, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->pix + (size_t)(a + c->dom_lo) * c->nx, pix_window, (size_t)cnt * c->nx,
+    HIP_TRY(hipMemsetAsync(c->pix, 0, (size_t)c->nxt * c->rows, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->pix + (size_t)(a + c->dom_lo) * c->nxt, pix_window, (size_t)cnt * c->nxt,
                            hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_image = true; c->have_matfree = false;
@@ -557,13 +556,13 @@ try {
     if (!s) return fail(DEFF_EINVAL, "slab is NULL");
     deff_ctx *c = s->ctx;
     TRY(use_device(c));
-    TRY(image_shape(c, c->nx, c->ny, 1, 1));
+    TRY(image_shape(c, c->nxt, c->ny, 1, 1));
     int a = 0, cnt = 0;
     TRY(deff_slab_rank_window(s, &a, &cnt));
-    HIP_TRY(hipMemsetAsync(c->pix, 0, c->n, c->stream));
-    const uint64_t first = img * (uint64_t)s->NY * (uint64_t)s->nx + (uint64_t)a * (uint64_t)s->nx;
-    hipLaunchKernelGGL(k_synth_mask_at, dim3(grid_for((size_t)cnt * c->nx)), dim3(256), 0, c->stream,
-                       c->pix + (size_t)(a + c->dom_lo) * c->nx, (size_t)cnt * c->nx, seed, first);
+    HIP_TRY(hipMemsetAsync(c->pix, 0, (size_t)c->nxt * c->rows, c->stream));
+    const uint64_t first = img * (uint64_t)s->NY * (uint64_t)s->nxt + (uint64_t)a * (uint64_t)s->nxt;
+    hipLaunchKernelGGL(k_synth_mask_at, dim3(grid_for((size_t)cnt * c->nxt)), dim3(256), 0, c->stream,
+                       c->pix + (size_t)(a + c->dom_lo) * c->nxt, (size_t)cnt * c->nxt, seed, first);
     HIP_TRY(hipGetLastError());
     c->have_image = true; c->have_matfree = false;
     return DEFF_OK;
@@ -576,8 +575,7 @@ try {
     if (!s || !x_own) return fail(DEFF_EINVAL, "NULL argument");
     deff_ctx *c = s->ctx;
     TRY(use_device(c));
-    HIP_TRY(hipMemcpyAsync(x_own, c->x[c->cur] + (size_t)c->own_lo * c->nx, sizeof(double) * (size_t)c->own_h * c->nx,
-                           hipMemcpyDeviceToHost, c->stream));
+    TRY(rows_d2h(c, x_own, (const double *)(c->x[c->cur] + (size_t)c->own_lo * c->nx), (size_t)c->own_h));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DEFF_OK;
 }

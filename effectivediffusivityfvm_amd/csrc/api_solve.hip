@@ -156,15 +156,14 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             int T = pl->T_override ? pl->T_override : (c->tb_T ? c->tb_T : default_tb_T(c));
             T = T >= 8 ? 8 : T >= 6 ? 6 : T >= 4 ? 4 : T >= 2 ? 2 : 1;
             pl->T = T;
-            pl->CPL = 2;
             // strips of 128 columns overlapping by 2*HW; a mesh wall needs no halo (kernels_tb.hpp)
-            const int hw = (T + 1) & ~1, wout = 64 * pl->CPL - 2 * hw;
+            const int hw = (T + 1) & ~1, wout = TB_COLS - 2 * hw;
             // placement A: every strip carries its halo, also outside the first column; placement B:
             // no halo outside a wall (kernels_tb.hpp).  B needs fewer strips for narrow images
             // (a 128-column image is ONE strip: 2x on dataset batches); where the counts tie, A measured
             // equal or up to 5 % faster in one process (T = 8 at 4096^2), so B is used only when it wins.
             const int ntx_a = (c->nx + wout - 1) / wout;
-            const int ntx_b = c->nx <= 64 * pl->CPL ? 1 : (c->nx - 64 * pl->CPL + wout - 1) / wout + 1;
+            const int ntx_b = c->nx <= TB_COLS ? 1 : (c->nx - TB_COLS + wout - 1) / wout + 1;
             const bool use_b = c->tb_wall_halo == 0 ? true : (c->tb_wall_halo == 1 ? false : ntx_b < ntx_a);
             pl->shift = use_b ? 0 : hw;
             pl->ntx = use_b ? ntx_b : ntx_a;

@@ -228,7 +228,7 @@ struct SweepPlan {
     int rows = 0, cpi = 0, gx = 0, gy = 0, blocks = 0;   // single-sweep kernels (cpi: row tiles per image)
     // temporally blocked kernel
     bool fma = false;
-    int T = 0, CPL = 2, LY = 0, tcpi = 0, ntx = 0, tgx = 0, tgy = 0, tblocks = 0;
+    int T = 0, LY = 0, tcpi = 0, ntx = 0, tgx = 0, tgy = 0, tblocks = 0;
     int shift = 0;                                        // column shift of the strips (0: no halo outside the walls)
     int T_override = 0;                                   // slab mode plans a T = 1 pass for remainders
     bool guard = false;

@@ -156,7 +156,6 @@ struct Slabs {
     ~Slabs() { deff_slab_group_destroy(g); }
     bool open(const Image &im, const Options &o, int nx, int ny)
     {
-        if (nx & 1) { std::fprintf(stderr, "deff2d: row slabs over several GPUs need an even mesh width (got %d)\n", nx); return false; }
         CK(deff_slab_group_create((int)devices.size(), devices.data(), nx, ny, &g));
         CK(deff_slab_group_set_tuning(g, "fma", g_contracted));
         std::vector<uint8_t> mesh_pix((size_t)nx * ny);              // the slabs take the image at mesh resolution

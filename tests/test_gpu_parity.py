@@ -435,6 +435,35 @@ def test_row_slabs_4096_equals_one_gpu(pkg, recorded):
         assert np.array_equal(g.get_field(), ref)
 
 
+def test_slabs_of_an_odd_width_image(pkg, oracle):
+    """Row slabs with padded device rows: 3 slabs of a 131-column image, full solve."""
+    nx, NY = 131, 90
+    rng = np.random.default_rng(31)
+    pix = rand_mask(rng, nx, NY, 0.5)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-2)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    x0 = rng.random((NY, nx))
+    it, deff, conv, x, MFL, MFR = oracle.jacobi(A, b, x0, D, 0.0, 1.0, 1e-3, 2000, check_every=100)
+    with pkg.SlabGroup(nx, NY, [0, 0, 0]) as g:
+        g.set_image(pix)
+        g.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+        g.set_field(x0)
+        assert np.array_equal(g.get_field(), x0)
+        r = g.solve(1e-3, 2000, check_every=100)
+        assert (r.iters, r.deff_raw, r.conv) == (it, deff, conv)
+        assert np.array_equal(r.MFL, MFL) and np.array_equal(r.MFR, MFR)
+        assert_field(g.get_field(), x)
+    with pkg.SlabGroup(nx, NY, [0, 0]) as g:                     # the generator through slab windows
+        g.synth_image(12345, 2)
+        g.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+        g.init_linear(0.0, 1.0)
+        g.sweeps(19)
+        pix2 = oracle.synth_mask(nx, NY, 12345, 2)
+        D2 = oracle.fill_D_2phase(pix2, 1.0, 1e-2)
+        A2, b2 = oracle.discretize(D2, 0.0, 1.0)
+        assert_field(g.get_field(), oracle.sweeps(A2, b2, oracle.linear_guess(nx, NY, 0.0, 1.0), 19))
+
+
 def test_rccl_slab_single_rank(pkg, oracle):
     """The process-per-GPU transport with a communicator of one rank (all a one-GPU box allows):
     RCCL init, the all-gather of the fluxes, the solve loop; no neighbour to exchange with."""
@@ -531,7 +560,7 @@ def test_slab_ranks_three_processes_one_gpu(pkg, oracle, tmp_path):
     (NY=203 over 3), a middle rank with two neighbours."""
     import socket
     import torch.multiprocessing as mp
-    nx, NY, world = 256, 203, 3
+    nx, NY, world = 255, 203, 3                      # odd width: padded device rows, host rows of 255
     rng = np.random.default_rng(5)
     pix = rand_mask(rng, nx, NY, 0.5)
     np.save(tmp_path / "pix.npy", pix)
