@@ -28,7 +28,7 @@ SYMBOLS = [
     "deff_slab_group_sweeps", "deff_slab_group_flux", "deff_slab_group_solve",
     "deff_rccl_unique_id", "deff_slab_rank_create", "deff_slab_rank_create_custom", "deff_slab_rank_destroy", "deff_slab_rank_layout",
     "deff_slab_rank_window", "deff_slab_rank_context", "deff_slab_rank_set_image_window",
-    "deff_slab_rank_synth_image", "deff_slab_rank_get_field", "deff_slab_rank_sweeps", "deff_slab_rank_solve",
+    "deff_slab_rank_synth_image", "deff_slab_rank_assemble_3phase", "deff_slab_group_assemble_3phase", "deff_slab_rank_get_field", "deff_slab_rank_sweeps", "deff_slab_rank_solve",
     "deff_solve_stream", "deff_get_slot_field", "deff_debug_tb_stamps", "deff_flux", "deff_set_progress", "deff_last_launches", "deff_device_field", "deff_synchronize",
 ]
 
@@ -132,6 +132,8 @@ def load():
     L.deff_slab_rank_context.argtypes = [ctx, C.POINTER(ctx)]
     L.deff_slab_rank_set_image_window.argtypes = [ctx, _u8p]
     L.deff_slab_rank_synth_image.argtypes = [ctx, C.c_uint64, C.c_uint64]
+    L.deff_slab_rank_assemble_3phase.argtypes = [ctx, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_double, C.c_double]
+    L.deff_slab_group_assemble_3phase.argtypes = [ctx, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_double, C.c_double]
     L.deff_slab_rank_get_field.argtypes = [ctx, _dp]
     L.deff_slab_rank_sweeps.argtypes = [ctx, C.c_int64, C.c_double, C.POINTER(C.c_float)]
     L.deff_slab_rank_solve.argtypes = [ctx, C.c_double, C.c_double, C.c_int64, C.c_int64, C.POINTER(Result),

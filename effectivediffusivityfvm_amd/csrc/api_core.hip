@@ -373,8 +373,8 @@ int explicit_from_image(deff_ctx *c)
     hipLaunchKernelGGL(k_fill_D_2phase, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->W, c->ampX,
                        c->ampY, c->nx, c->nxt, c->ny, c->rows, c->Df, c->Ds, D);
     hipLaunchKernelGGL(k_assemble_from_D, dim3(grid_for(c->n)), dim3(256), 0, c->stream, D,
-                       (const unsigned int *)nullptr, c->nx, c->nxt, c->ny, c->rows, c->dx, c->dy, c->CL, c->CR,
-                       soa_of(c));
+                       (const unsigned int *)nullptr, c->nx, c->nxt, c->ny, c->rows, c->dom_lo, c->mesh_ny, c->dx,
+                       c->dy, c->CL, c->CR, soa_of(c));
     HIP_TRY(hipGetLastError());
     c->have_explicit = true;
     c->c0_omega = NAN;
@@ -405,7 +405,7 @@ try {
     hipLaunchKernelGGL(k_fill_D_3phase, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->W, c->ampX,
                        c->ampY, c->nx, c->nxt, c->ny, c->rows, Df, Ds, Dg, dD);
     hipLaunchKernelGGL(k_assemble_from_D, dim3(grid_for(c->n)), dim3(256), 0, c->stream, dD, dG, c->nx, c->nxt,
-                       c->ny, c->rows, c->dx, c->dy, CL, CR, soa_of(c));
+                       c->ny, c->rows, c->dom_lo, c->mesh_ny, c->dx, c->dy, CL, CR, soa_of(c));
     hipLaunchKernelGGL(k_wall_D_from_D, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, dD, c->nx, c->nxt,
                        c->rows, c->Dl, c->Dr);
     HIP_TRY(hipGetLastError());
@@ -468,7 +468,7 @@ try {
     if (Grid) TRY(rows_h2d(c, dG, Grid, (size_t)c->rows));
     c->CL = CL; c->CR = CR;
     hipLaunchKernelGGL(k_assemble_from_D, dim3(grid_for(c->n)), dim3(256), 0, c->stream, dD, dG, c->nx, c->nxt,
-                       c->ny, c->rows, c->dx, c->dy, CL, CR, soa_of(c));
+                       c->ny, c->rows, c->dom_lo, c->mesh_ny, c->dx, c->dy, CL, CR, soa_of(c));
     hipLaunchKernelGGL(k_wall_D_from_D, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, dD, c->nx, c->nxt,
                        c->rows, c->Dl, c->Dr);
     HIP_TRY(hipGetLastError());

@@ -169,6 +169,29 @@ try {
 }
 DEFF_API_CATCH
 
+// 3-phase system over the slabs (deff_assemble_3phase per slab): Grid is the whole image's flood-fill
+// result (NY x nx, may be NULL); every slab takes the rows of its array window.  The explicit planes
+// are harvested into a row dictionary per slab at the first sweep, so the slabs still run on the
+// temporally blocked kernel; a system with too many distinct rows is refused by the sweep planner.
+extern "C" int deff_slab_group_assemble_3phase(deff_slab_group *g, double Ds, double Df, double Dg,
+                                               const unsigned int *Grid, double CL, double CR)
+try {
+    if (!g) return fail(DEFF_EINVAL, "group is NULL");
+    std::vector<unsigned int> win;
+    for (int r = 0; r < g->n; ++r) {
+        deff_ctx *c = g->ctx[r];
+        if (Grid) {
+            int m0, a0, cnt;
+            slab_window(g, r, &m0, &a0, &cnt);
+            win.assign((size_t)c->rows * c->nxt, 0u);
+            memcpy(&win[(size_t)a0 * c->nxt], Grid + (size_t)m0 * c->nxt, sizeof(unsigned int) * (size_t)cnt * c->nxt);
+        }
+        TRY(deff_assemble_3phase(c, Ds, Df, Dg, Grid ? win.data() : nullptr, CL, CR));
+    }
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
 extern "C" int deff_slab_group_init_linear(deff_slab_group *g, double CL, double CR)
 try {
     if (!g) return fail(DEFF_EINVAL, "group is NULL");
@@ -548,6 +571,24 @@ try {
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_image = true; c->have_matfree = false;
     return DEFF_OK;
+}
+DEFF_API_CATCH
+
+// 3-phase system of this rank's slab; Grid_window = the rows deff_slab_rank_window() names of the
+// image's flood-fill result (or NULL)
+extern "C" int deff_slab_rank_assemble_3phase(deff_slab_rank *s, double Ds, double Df, double Dg,
+                                              const unsigned int *Grid_window, double CL, double CR)
+try {
+    if (!s) return fail(DEFF_EINVAL, "slab is NULL");
+    deff_ctx *c = s->ctx;
+    std::vector<unsigned int> win;
+    if (Grid_window) {
+        int a = 0, cnt = 0;
+        TRY(deff_slab_rank_window(s, &a, &cnt));
+        win.assign((size_t)c->rows * c->nxt, 0u);
+        memcpy(&win[(size_t)(a + c->dom_lo) * c->nxt], Grid_window, sizeof(unsigned int) * (size_t)cnt * c->nxt);
+    }
+    return deff_assemble_3phase(c, Ds, Df, Dg, Grid_window ? win.data() : nullptr, CL, CR);
 }
 DEFF_API_CATCH
 

@@ -13,7 +13,7 @@
 // --arith contracted: products fused into adds the way a compiler contracts the reference's expressions
 // (kernels_sweep.hpp); default is the reference's written operation order.
 //
-// --devices with RunBatch 0 and two phases: the one image is split into row slabs over the listed GPUs.
+// --devices with RunBatch 0: the one image (2 or 3 phases) is split into row slabs over the listed GPUs.
 // --devices: batch mode over several GPUs from one process -- one host thread and one solver context
 // per listed device, images handed out from a shared counter, no inter-GPU communication.
 //
@@ -148,6 +148,19 @@ struct OneGpu {
         return true;
     }
     bool get_field(double *x) { CK(deff_get_field(S.ctx, x)); return true; }
+    bool assemble3(const Options &o, double DCG, const unsigned int *grid)
+    {
+        CK(deff_assemble_3phase(S.ctx, o.DCsolid, o.DCfluid, DCG, grid, o.CLeft, o.CRight));
+        return true;
+    }
+    bool solve_with(const Options &o, double tol, int64_t max_iter, bool show, double *scale, deff_result *r)
+    {
+        if (show && o.verbose == 1 && !o.BatchFlag) deff_set_progress(S.ctx, progress, scale);
+        const int rc = deff_solve(S.ctx, 2.0 / 3.0, tol, max_iter, 10000, r, nullptr, nullptr);
+        deff_set_progress(S.ctx, nullptr, nullptr);
+        CK(rc);
+        return true;
+    }
 };
 
 struct Slabs {
@@ -174,6 +187,16 @@ struct Slabs {
         return true;
     }
     bool get_field(double *x) { CK(deff_slab_group_get_field(g, x)); return true; }
+    bool assemble3(const Options &o, double DCG, const unsigned int *grid)
+    {
+        CK(deff_slab_group_assemble_3phase(g, o.DCsolid, o.DCfluid, DCG, grid, o.CLeft, o.CRight));
+        return true;
+    }
+    bool solve_with(const Options &, double tol, int64_t max_iter, bool, double *, deff_result *r)
+    {
+        CK(deff_slab_group_solve(g, 2.0 / 3.0, tol, max_iter, 10000, r, nullptr, nullptr));
+        return true;
+    }
 };
 
 // 2-phase image.  single = SingleSim's DCF ramp 100, 1e4, ... up to Df (cuh:1759-1817);
@@ -230,22 +253,21 @@ static bool solve_2phase(Target &&T, const Image &im, const Options &o, bool sin
 }
 
 // 3-phase image: FloodFill on pixels > 200, DCG continuation (cuh:1443-1597).
-static bool solve_3phase(Session &S, const Image &im, const Options &o, Row *row, std::vector<double> *field)
+template <class Target>
+static bool solve_3phase(Target &&T, const Image &im, const Options &o, Row *row, std::vector<double> *field)
 {
     const int nx = im.W * o.MeshIncreaseX, ny = im.H * o.MeshIncreaseY;
-    if (!S.prepare(nx, ny)) return false;
     row->nElements = nx * ny;
     std::vector<unsigned int> grid = grid_of(im, o, 200);
     CK(deff_flood_fill(grid.data(), nx, ny, &row->path));
-    CK(deff_set_image(S.ctx, im.pix.data(), im.W, im.H, o.MeshIncreaseX, o.MeshIncreaseY));
-    CK(deff_init_linear(S.ctx, o.CLeft, o.CRight));
+    if (!T.open(im, o, nx, ny)) return false;
     const double DCF = o.DCfluid, DCG = o.DCgas, DCS = o.DCsolid;
     int stage_no = 1;
     for (double g = 10; g < DCG; g *= 10, ++stage_no) {              // JacobiGPUPreCond stages, cuh:1492-1549
         if (o.verbose == 1) std::printf("Pre-Cond Stage %d: DCG = %1.3e\n", stage_no, g);
-        CK(deff_assemble_3phase(S.ctx, DCS, DCF, g, grid.data(), o.CLeft, o.CRight));
+        if (!T.assemble3(o, g, grid.data())) return false;
         deff_result r;
-        CK(deff_solve(S.ctx, 2.0 / 3.0, o.ConvergeCriteria * 10, 1000000, 10000, &r, nullptr, nullptr));
+        if (!T.solve_with(o, o.ConvergeCriteria * 10, 1000000, false, nullptr, &r)) return false;
         if (o.verbose == 1) std::printf("Iterations taken = %ld\n", (long)r.iters);
         row->stages.push_back((long)r.iters);
     }
@@ -262,12 +284,10 @@ static bool solve_3phase(Session &S, const Image &im, const Options &o, Row *row
             }
         row->SVF = s; row->LVF = l;
     }
-    CK(deff_assemble_3phase(S.ctx, DCS, DCF, DCG, grid.data(), o.CLeft, o.CRight));
+    if (!T.assemble3(o, DCG, grid.data())) return false;
     deff_result r;
     double scale = DCF;
-    if (o.verbose == 1 && !o.BatchFlag) deff_set_progress(S.ctx, progress, &scale);
-    CK(deff_solve(S.ctx, 2.0 / 3.0, o.ConvergeCriteria, o.MAX_ITER, 10000, &r, nullptr, nullptr));
-    deff_set_progress(S.ctx, nullptr, nullptr);
+    if (!T.solve_with(o, o.ConvergeCriteria, o.MAX_ITER, true, &scale, &r)) return false;
     if (o.verbose == 1) std::printf("Iterations taken = %ld\n", (long)r.iters);
     row->stages.push_back((long)r.iters);
     row->iters = (long)r.iters;
@@ -275,7 +295,7 @@ static bool solve_3phase(Session &S, const Image &im, const Options &o, Row *row
     row->conv = r.conv;
     row->seconds = r.loop_ms / 1000.0;                                // JacobiGPUPreCond does not add to gpuTime, cuh:1147
     if (o.verbose == 1) std::printf("DCF = %g, Deff %g\n", DCF, row->deff);
-    if (field) { field->resize((size_t)nx * ny); CK(deff_get_field(S.ctx, field->data())); }
+    if (field) { field->resize((size_t)nx * ny); if (!T.get_field(field->data())) return false; }
     return true;
 }
 
@@ -696,10 +716,13 @@ int main(int argc, char **argv)
             rows[(size_t)k] = Row();
             rows[(size_t)k].name = image_name(k);
             std::vector<double> field;
-            const bool slabs = o.nPhase == 2 && !o.BatchFlag && devices.size() >= 2;   // one image over several GPUs
-            const bool ok = slabs ? solve_2phase(Slabs{devices}, im, o, true, &rows[(size_t)k], want_field ? &field : nullptr)
-                            : (o.nPhase == 2) ? solve_2phase(OneGpu{S}, im, o, !o.BatchFlag, &rows[(size_t)k], want_field ? &field : nullptr)
-                                              : solve_3phase(S, im, o, &rows[(size_t)k], want_field ? &field : nullptr);
+            const bool slabs = !o.BatchFlag && devices.size() >= 2;             // one image over several GPUs
+            std::vector<double> *fp = want_field ? &field : nullptr;
+            Row *rw = &rows[(size_t)k];
+            const bool ok = (o.nPhase == 2) ? (slabs ? solve_2phase(Slabs{devices}, im, o, true, rw, fp)
+                                                     : solve_2phase(OneGpu{S}, im, o, !o.BatchFlag, rw, fp))
+                                            : (slabs ? solve_3phase(Slabs{devices}, im, o, rw, fp)
+                                                     : solve_3phase(OneGpu{S}, im, o, rw, fp));
             if (!ok) { failed = true; return; }
             if (o.verbose == 1 && o.nPhase == 2) std::printf("Porosity = %g\n", rows[(size_t)k].porosity);
             progress_append(progress_path, k, rows[(size_t)k]);

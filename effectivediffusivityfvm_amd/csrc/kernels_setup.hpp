@@ -153,25 +153,29 @@ struct CoefSoA {
 // General assembly from a per-cell D array (DiscretizeMatrix2D cuh:815-902;
 // with Grid != nullptr, DiscretizeMatrix2D_ImpSolid cuh:715-812: Grid 1 or 2
 // gets the identity row, cuh:750-752).
+// dom_lo / mesh_ny as in k_phase_codes: array row li of an image is mesh row li - dom_lo of a
+// mesh_ny-row mesh (a row slab's array is a window with halo rows; rows outside the mesh and the
+// pad column get the identity row and stay 0).
 static __global__ void k_assemble_from_D(const double *__restrict__ D, const unsigned int *__restrict__ Grid,
-                                  int nx, int nxt, int ny, int rows, double dx, double dy, double CL, double CR,
-                                  CoefSoA c)
+                                  int nx, int nxt, int ny, int rows, int dom_lo, int mesh_ny, double dx, double dy,
+                                  double CL, double CR, CoefSoA c)
 {
     const size_t n = (size_t)nx * rows;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n;
          p += (size_t)gridDim.x * blockDim.x) {
-        int i = (int)(p / nx) % ny, j = (int)(p % nx);   // i: row inside its image
+        const int li = (int)(p / nx) % ny, j = (int)(p % nx);   // li: row inside its image's array
+        const int gi = li - dom_lo;                            // mesh row
         FvmRow r;
-        if (j >= nxt || (Grid != nullptr && (Grid[p] == 1 || Grid[p] == 2))) {    // pad column: identity row too
+        if (j >= nxt || gi < 0 || gi >= mesh_ny || (Grid != nullptr && (Grid[p] == 1 || Grid[p] == 2))) {
             r.a0 = 1; r.aW = 0; r.aE = 0; r.aS = 0; r.aN = 0; r.b = 0;
         } else {
             // clamped neighbour reads; values at clamped positions are unused
             double Dp = D[p];
             double Dw = D[j > 0 ? p - 1 : p];
             double De = D[j < nxt - 1 ? p + 1 : p];
-            double Ds = D[i < ny - 1 ? p + nx : p];
-            double Dn = D[i > 0 ? p - nx : p];
-            r = fvm_row(Dp, Dw, De, Ds, Dn, pos_class(j, nxt), pos_class(i, ny), dx, dy, CL, CR);
+            double Ds = D[(gi < mesh_ny - 1 && li < ny - 1) ? p + nx : p];
+            double Dn = D[(gi > 0 && li > 0) ? p - nx : p];
+            r = fvm_row(Dp, Dw, De, Ds, Dn, pos_class(j, nxt), pos_class(gi, mesh_ny), dx, dy, CL, CR);
         }
         c.a0[p] = r.a0; c.aW[p] = r.aW; c.aE[p] = r.aE; c.aS[p] = r.aS; c.aN[p] = r.aN; c.b[p] = r.b;
     }

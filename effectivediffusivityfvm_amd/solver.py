@@ -287,6 +287,15 @@ class SlabGroup:
     def assemble_2phase(self, Ds, Df, CL, CR):
         check(self._L.deff_slab_group_assemble_2phase(self._g, Ds, Df, CL, CR))
 
+    def assemble_3phase(self, Ds, Df, Dg, CL, CR, grid=None):
+        """grid: the whole image's flood-fill result (NY, nx) uint32, or None."""
+        g = None
+        if grid is not None:
+            grid = np.ascontiguousarray(grid, dtype=np.uint32)
+            assert grid.shape == (self.ny, self.nx)
+            g = grid.ctypes.data_as(C.c_void_p)
+        check(self._L.deff_slab_group_assemble_3phase(self._g, Ds, Df, Dg, g, CL, CR))
+
     def init_linear(self, CL, CR):
         check(self._L.deff_slab_group_init_linear(self._g, CL, CR))
 
@@ -445,6 +454,15 @@ class SlabRank:
 
     def assemble_2phase(self, Ds, Df, CL, CR):
         check(self._L.deff_assemble_2phase(self._ctx, Ds, Df, CL, CR))
+
+    def assemble_3phase(self, Ds, Df, Dg, CL, CR, grid_full=None):
+        """grid_full: the whole image's flood-fill result (NY, nx); this rank passes its window of it."""
+        g = None
+        if grid_full is not None:
+            a, n = self.window()
+            win = np.ascontiguousarray(grid_full[a:a + n], dtype=np.uint32)
+            g = win.ctypes.data_as(C.c_void_p)
+        check(self._L.deff_slab_rank_assemble_3phase(self._s, Ds, Df, Dg, g, CL, CR))
 
     def init_linear(self, CL, CR):
         check(self._L.deff_init_linear(self._ctx, CL, CR))

@@ -176,6 +176,9 @@ int deff_slab_group_set_tuning(deff_slab_group *g, const char *key, int value);
 int deff_slab_group_set_image(deff_slab_group *g, const uint8_t *pix /* NY*nx */);
 int deff_slab_group_synth_image(deff_slab_group *g, uint64_t seed, uint64_t img);
 int deff_slab_group_assemble_2phase(deff_slab_group *g, double Ds, double Df, double CL, double CR);
+/* 3-phase system (deff_assemble_3phase per slab); Grid = flood-fill result of the whole image, NY*nx, or NULL */
+int deff_slab_group_assemble_3phase(deff_slab_group *g, double Ds, double Df, double Dg, const unsigned int *Grid,
+                                    double CL, double CR);
 int deff_slab_group_init_linear(deff_slab_group *g, double CL, double CR);
 int deff_slab_group_set_field(deff_slab_group *g, const double *x /* NY*nx */);
 int deff_slab_group_get_field(deff_slab_group *g, double *x /* NY*nx */);
@@ -206,6 +209,9 @@ int deff_slab_rank_layout(const deff_slab_rank *s, int *first_row, int *row_coun
 int deff_slab_rank_window(const deff_slab_rank *s, int *first_row, int *row_count);   /* rows it holds */
 int deff_slab_rank_context(deff_slab_rank *s, deff_ctx **ctx);   /* for set_tuning / assemble_2phase / init_linear */
 int deff_slab_rank_set_image_window(deff_slab_rank *s, const uint8_t *pix_window);
+/* 3-phase system of this rank's slab; Grid_window = the rows deff_slab_rank_window() names, or NULL */
+int deff_slab_rank_assemble_3phase(deff_slab_rank *s, double Ds, double Df, double Dg, const unsigned int *Grid_window,
+                                   double CL, double CR);
 int deff_slab_rank_synth_image(deff_slab_rank *s, uint64_t seed, uint64_t img);
 int deff_slab_rank_get_field(deff_slab_rank *s, double *x_own);
 int deff_slab_rank_sweeps(deff_slab_rank *s, int64_t n, double omega, float *ms);

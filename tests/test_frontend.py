@@ -192,6 +192,13 @@ def test_driver_3phase_as_shipped(built, tmp_path, recorded):
     assert res["stage_iterations"] == rec["stage_sweeps"]
     assert res["Deff"] == rec["deff"] and res["converge"] == rec["conv"] and res["SVF"] == rec["SVF"]
     assert "Pre-Cond Stage 6: DCG = 1.000e+06" in r.stdout and "Iteration = 0, Deff = " in r.stdout
+    # the same input over three row slabs (--devices): identical numbers
+    r2 = subprocess.run([EXE, "--json", "res_slabs.json", "--devices", "0,0,0"], cwd=tmp_path, capture_output=True,
+                        text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr + r2.stdout
+    res2 = json.load(open(tmp_path / "res_slabs.json"))["results"][0]
+    assert "Row slabs over 3 GPUs" in r2.stdout
+    assert res2["stage_iterations"] == rec["stage_sweeps"] and res2["Deff"] == rec["deff"] and res2["converge"] == rec["conv"]
     rows = open(tmp_path / "singleTest.csv").read().splitlines()
     assert rows[0] == "imgNum,SVF,LVF,PathFlag,Deff,Time,nElements,converge,ds,df,dg"
     assert rows[1].startswith("00000.jpg,0.653931,0.000000,1,2.247e+05,")

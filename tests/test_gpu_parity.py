@@ -215,6 +215,23 @@ def test_img00000_3phase_as_shipped(pkg, oracle, recorded, img00000):
     assert np.all(np.abs(field[solid]) < 1e-300)          # impermeable solid decays to 0 (x <- x/3 per sweep)
 
 
+def test_img00000_3phase_as_shipped_over_row_slabs(pkg, oracle, recorded, img00000):
+    """The same as-shipped 3-phase run with the image split into three row slabs: every slab harvests
+    its own row dictionary; stage sweeps, Deff, conv and the field are those of the one-GPU run."""
+    from effectivediffusivityfvm_amd import batch
+    rec = recorded["img00000_3phase_as_shipped"]
+    o = rec["options"]
+    with pkg.SlabGroup(128, 128, [0, 0, 0]) as g:
+        r = batch.solve_image_3phase(g, img00000, o["Ds"], o["Df"], o["Dg"], o["CL"], o["CR"], o["tol"],
+                                     o["max_iter"])
+        field = g.get_field()
+    assert r["stage_sweeps"] == rec["stage_sweeps"]
+    assert r["deff"] == rec["deff"] and r["conv"] == rec["conv"]
+    with np.errstate(all="ignore"):
+        want = oracle.solve_3phase(img00000, o["Ds"], o["Df"], o["Dg"], o["CL"], o["CR"], o["tol"], o["max_iter"])
+    assert_field(field, want["field"])
+
+
 def test_3phase_assembly_with_grid_and_amplification(pkg, oracle):
     rng = np.random.default_rng(9)
     pix = rng.choice(np.array([0, 30, 120, 150, 199, 201, 255], dtype=np.uint8), size=(9, 11))
@@ -533,7 +550,7 @@ def test_rccl_slabs_two_ranks(pkg, oracle, tmp_path):
         assert tuple(np.load(tmp_path / f"r{k}.npy")) == (it, deff, conv)
 
 
-def _gloo_slab_worker(rank, world, port, nx, NY, out_dir):
+def _gloo_slab_worker(rank, world, port, nx, NY, out_dir, three_phase=False):
     import sys
     from conftest import ROOT
     sys.path.insert(0, ROOT)
@@ -544,7 +561,10 @@ def _gloo_slab_worker(rank, world, port, nx, NY, out_dir):
     pix = np.load(os.path.join(out_dir, "pix.npy"))
     with pkg.SlabRank(nx, NY, rank, world, device=0, transport=TorchDistTransport()) as s:
         s.set_image(pix)
-        s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+        if three_phase:
+            s.assemble_3phase(0.0, 1.0, 50.0, 0.0, 1.0, grid_full=np.load(os.path.join(out_dir, "grid.npy")))
+        else:
+            s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
         s.init_linear(0.0, 1.0)
         r = s.solve(1e-3, 2000, check_every=100)
         np.save(os.path.join(out_dir, f"x{rank}.npy"), s.get_field())
@@ -728,6 +748,33 @@ def test_fma_mode_config1_gives_the_surveys_primary_value(pkg, oracle, recorded,
     assert r.iters == rec["iters"]
     assert r.deff_raw == rec["deff_build_a"]
     assert r.conv == rec["conv_build_a"]
+
+
+def test_slab_ranks_three_phase_three_processes(pkg, oracle, tmp_path):
+    """3-phase (impermeable solid, flood-filled Grid) through the per-rank slab path: three
+    processes, custom transport, each rank assembling its window of the Grid."""
+    import socket
+    import torch.multiprocessing as mp
+    nx, NY, world = 130, 96, 3
+    rng = np.random.default_rng(6)
+    pix = rng.choice(np.array([0, 120, 255], dtype=np.uint8), size=(NY, nx), p=[0.35, 0.4, 0.25])
+    grid, _ = oracle.floodfill((pix > 200).astype(np.uint32))
+    np.save(tmp_path / "pix.npy", pix)
+    np.save(tmp_path / "grid.npy", grid)
+    D = oracle.fill_D_3phase(pix, 1.0, 0.0, 50.0)
+    with np.errstate(all="ignore"):
+        A, b = oracle.discretize(D, 0.0, 1.0, grid=grid)
+        it, deff, conv, x, MFL, _ = oracle.jacobi(A, b, oracle.linear_guess(nx, NY, 0.0, 1.0), D, 0.0, 1.0, 1e-3, 2000,
+                                                  check_every=100)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    mp.spawn(_gloo_slab_worker, args=(world, port, nx, NY, str(tmp_path), True), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f"x{k}.npy") for k in range(world)])
+    assert_field(got, x)
+    for k in range(world):
+        assert tuple(np.load(tmp_path / f"r{k}.npy")) == (it, deff, conv)
+        assert np.array_equal(np.load(tmp_path / f"mfl{k}.npy"), MFL)
 
 
 def test_host_assembled_system_drop_in(pkg, oracle):
