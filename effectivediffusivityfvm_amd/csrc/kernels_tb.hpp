@@ -31,7 +31,8 @@
 
 namespace deff {
 
-constexpr int TB_COLS = 128;                                   // columns per wave strip (2 per lane)
+constexpr int TB_COLS = 128;
+template <bool V> struct TbTag { static constexpr bool value = V; };                                   // columns per wave strip (2 per lane)
 
 // lane i <- lane i-1 (lane 0 <- 0.0)
 __device__ __forceinline__ double from_lane_below(double v)
@@ -163,7 +164,16 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
     // self-balancing s_setprio -- each wave lowering its priority as it advances -- narrowed that to
     // 88..119 us but left the back-to-back launch rate unchanged (the SIMDs are throughput-bound;
     // the early finishers' share goes to the rest), so it is not kept.)
-    for (int r = r_begin; r < r_end; r += 3) {
+    // One group of three steps (input rows r, r+1, r+2).  TRIM = the group may contain levels whose
+    // output row this chunk does not need: sweep t needs rows from max(mesh top, ry0 - (T - t)) on, and
+    // produces row rr - t at the step that reads row rr, so for the first 2T steps of a chunk (T at the
+    // top of the mesh) part of the levels would only compute rows nothing reads -- 72 of 528 level
+    // steps at T = 8 with 50-row chunks.  The trimmed groups skip them behind wave-uniform branches;
+    // the steady-state loop below stays branch-free (a branch around every level of every step was
+    // measured 8 % slower).  A skipped level leaves its window slot as it was: finite values that are
+    // read only through zero links or not at all.
+    auto group = [&](const int r, auto trim_tag) __attribute__((always_inline)) {
+        constexpr bool TRIM = decltype(trim_tag)::value;
         double2 cur_x[3];
         unsigned cur_c[3];
 #pragma unroll
@@ -189,6 +199,12 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
 #pragma unroll
             for (int t = 1; t <= T; ++t) {
                 const int rt = rr - t;             // row produced by sweep t in this step
+                if constexpr (TRIM) {
+                    if (rt < row_lo || rt - t < ry0 - T) {   // wave-uniform: above the mesh / above this level's halo
+                        __builtin_amdgcn_sched_barrier(0);
+                        continue;
+                    }
+                }
                 const double2 vN = w[t - 1][sN], vC = w[t - 1][sC], vS = w[t - 1][sS];
                 const double xw0 = from_lane_below(vC.y);
                 const double xe1 = from_lane_above(vC.x);
@@ -207,7 +223,11 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-    }
+    };
+    constexpr int TRIMMED = ((2 * T + 2) / 3) * 3;   // steps that may hold unneeded levels, rounded up to whole groups
+    int r = r_begin;
+    for (; r < r_begin + TRIMMED && r < r_end; r += 3) group(r, TbTag<true>{});
+    for (; r < r_end; r += 3) group(r, TbTag<false>{});
 }
 
 // grid: persistent workgroups of 4 waves.  Wave tiles (strip tx, chunk ty) are numbered
