@@ -734,6 +734,34 @@ def test_fma_mode_three_phase_guarded_rows(pkg, oracle):
             assert_field(s.get_field(), ref)
 
 
+def test_fma_mode_through_stream_and_slabs(pkg, oracle):
+    """The arithmetic switch reaches the streaming batch (its own linear guesses) and the row slabs."""
+    nx, ny = 130, 72
+    rng = np.random.default_rng(41)
+    imgs = [rand_mask(rng, nx, ny, 0.5) for _ in range(4)]
+    want = []
+    for im in imgs:
+        D = oracle.fill_D_2phase(im, 1.0, 1e-2)
+        A, b = oracle.discretize(D, 0.1, 0.9)
+        want.append(oracle.jacobi(A, b, oracle.linear_guess(nx, ny, 0.1, 0.9, flavour="fma"), D, 0.1, 0.9, 1e-3, 2000,
+                                  check_every=100, flavour="fma"))
+    with pkg.Solver(nx, ny, nimg=2) as s:
+        s.set_tuning("fma", 1)
+        got = s.solve_stream(imgs, 1e-2, 1.0, 0.1, 0.9, 1e-3, 2000, check_every=100, want_fields=True)
+        for k, (it, deff, conv, xk, _, _) in enumerate(want):
+            assert (got[k].iters, got[k].deff_raw, got[k].conv) == (it, deff, conv)
+            assert_field(got[k].field, xk)
+    with pkg.SlabGroup(nx, ny, [0, 0, 0]) as g:
+        g.set_tuning("fma", 1)
+        g.set_image(imgs[0])
+        g.assemble_2phase(1e-2, 1.0, 0.1, 0.9)
+        g.init_linear(0.1, 0.9)
+        r = g.solve(1e-3, 2000, check_every=100)
+        it, deff, conv, xk, _, _ = want[0]
+        assert (r.iters, r.deff_raw, r.conv) == (it, deff, conv)
+        assert_field(g.get_field(), xk)
+
+
 def test_fma_mode_config1_gives_the_surveys_primary_value(pkg, oracle, recorded, img00000):
     """Config #1 end to end in contracted arithmetic: 110 001 sweeps and the Deff / conv the survey
     recorded first for the reference (build a); the default arithmetic gives build b
