@@ -90,7 +90,7 @@ int deff_get_plan(deff_ctx *ctx, const char *key, int *value);
 /* ---- image -> phases: replaces the mask->D loops cuh:1988-2000 (2-phase),
  *      cuh:1518-1529 (3-phase) and the synthetic generator of SURVEY.md 8d */
 int deff_set_image(deff_ctx *ctx, const uint8_t *pix, int W, int H, int ampX, int ampY);
-int deff_synth_image(deff_ctx *ctx, uint64_t seed, uint64_t img);   /* generated on the device */
+int deff_synth_image(deff_ctx *ctx, uint64_t seed, uint64_t img);   /* generated on the device; a stack holds images img, img+1, ... */
 int deff_get_image(deff_ctx *ctx, uint8_t *pix);                    /* W*H bytes back */
 
 /* grayscale JPEG file -> bytes: replaces readImage cuh:327-345 (stbi_load(..., 1)); decodes to the

@@ -99,6 +99,27 @@ def test_synth_generator_matches_oracle(pkg, oracle):
             assert np.array_equal(s.get_image(), oracle.synth_mask(nx, ny, 12345, img))
 
 
+def test_launch_plan_is_reported(pkg):
+    """deff_get_plan: whole-image tiles for a stack of small images, many short chunks for one big image."""
+    with pkg.Solver(128, 128, nimg=64) as s:
+        assert s.plan()["tb_T"] == 0                       # nothing planned yet
+        s.synth_image(1, 0)
+        s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(12)
+        p = s.plan()
+        assert p["tb_T"] in (4, 6, 8) and p["tb_strips"] == 1 and p["tb_LY"] * p["tb_chunks_per_image"] >= 128
+        assert p["tb_LY"] >= p["tb_T"] and p["tb_blocks"] % 8 == 0
+    with pkg.Solver(1024, 1024) as s:
+        s.synth_image(1, 0)
+        s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        s.set_tuning("tb_T", 8)
+        s.sweeps(16)
+        p = s.plan()
+        assert p["tb_T"] == 8 and p["tb_strips"] == 9 and p["tb_LY"] >= 8      # 128 + 8 x 112 columns, no halo outside the walls
+
+
 def test_synthetic_stack_holds_consecutive_images(pkg, oracle):
     """synth_image(seed, img) on a stack of B images = images img .. img+B-1 of the sequence."""
     nx, ny, B = 70, 48, 3
