@@ -29,6 +29,10 @@ with tempfile.TemporaryDirectory() as d:
     runs = [("grouped", [])]
     if N >= 12288:
         runs.append(("grouped_1024_slots", ["--batch-size", "1024"]))
+    if os.environ.get("DEFF_TWO_WORKERS"):
+        # two host threads + contexts + streams on ONE GPU: the tail of one stream's launch overlaps the other's head
+        runs.append(("two_workers_one_gpu", ["--devices", "0,0"]))
+        runs.append(("three_workers_one_gpu", ["--devices", "0,0,0"]))
     runs.append(("one_at_a_time", ["--batch-size", "1"]))
     for label, extra in runs:
         if label == "one_at_a_time" and N > 64:
