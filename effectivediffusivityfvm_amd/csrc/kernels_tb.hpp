@@ -23,7 +23,8 @@
 // HBM traffic per cell per sweep: (8 + 2) / T / efficiency read + 8 / T
 // written -- 2.7 B measured at T = 8 against 18 B for the single-sweep
 // matrix-free kernel and 64 B for explicit coefficients; the kernel is bound by
-// FP64 VALU issue and LDS lookups (SQ counters: VALU ~55-60 % busy, LDS ~40 %).
+// how many waves of a SIMD are ready to issue FP64 (SQ counters: VALU ~50-60 % busy, LDS ~40 %;
+// see the notes at tb_strip and DESIGN.md section 4).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,8 +32,8 @@
 
 namespace deff {
 
-constexpr int TB_COLS = 128;
-template <bool V> struct TbTag { static constexpr bool value = V; };                                   // columns per wave strip (2 per lane)
+constexpr int TB_COLS = 128;                                   // columns per wave strip (2 per lane)
+template <bool V> struct TbTag { static constexpr bool value = V; };   // compile-time flag for generic lambdas
 
 // lane i <- lane i-1 (lane 0 <- 0.0)
 __device__ __forceinline__ double from_lane_below(double v)
