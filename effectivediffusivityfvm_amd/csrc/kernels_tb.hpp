@@ -110,7 +110,13 @@ __device__ __forceinline__ double tb_cell(const double *lut, unsigned off, doubl
 // 0-3 %.  What bounds the kernel (tools/ubench): an FP64 instruction with VGPR-pair sources issues once
 // per 8 clocks from ONE wave whatever the ILP, and reaches the 4-clock rate only with two waves of
 // the SIMD ready at once -- with 3-4 resident waves that are parked on LDS part of the time, the
-// SIMD sees one or two.  Only more resident waves would help, and the registers are spent.  The
+// SIMD sees one or two.  Only more resident waves would help, and the registers are spent;
+// cooperating strips -- the 4 waves of a workgroup on 4 adjacent windows WITHOUT overlap, the edge
+// columns of every level handed over through an LDS mailbox with one s_barrier per step, so that
+// only the outer sides of a 512-column super-strip carry a halo (33 instead of 37 strips of work at
+// 4096 columns) -- 856 against 1 138 G cells*iter/s at T=8 (168 VGPRs): the lock-step of waves that
+// sit on four different SIMDs and the mailbox read at the head of every level's dependency chain
+// cost far more than the 11 % of work saved.  Independence of the waves is worth its redundancy.  The
 // code is deliberately written with double2 values and named slots: an array-of-scalars
 // formulation of the same dataflow made hipcc hoist the lookups to 204 VGPRs.)
 template <int T, bool GUARD, bool WALL, bool FMA>
