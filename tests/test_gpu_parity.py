@@ -700,6 +700,63 @@ def test_odd_width_three_phase_batch_and_stream(pkg, oracle):
             assert_field(r.field, xk)
 
 
+# ---- randomised small cases -----------------------------------------------------------------
+
+def test_random_small_cases_all_paths(pkg, oracle):
+    """240 seeded random configurations -- mesh 2..150 x 2..90 (odd and even), 1-3 stacked images,
+    every kernel, every T, both arithmetics, 2 phases / 3 phases with a flood-filled Grid, random
+    diffusivities and wall values, 1..40 sweeps -- each compared bit for bit with the oracle."""
+    rng = np.random.default_rng(20261004)
+    for case in range(240):
+        nx, ny = int(rng.integers(2, 151)), int(rng.integers(2, 91))
+        nimg = int(rng.choice([1, 1, 2, 3]))
+        kernel = str(rng.choice(["auto", "matfree_tb", "matfree", "explicit", "scalar"]))
+        T = int(rng.choice([0, 1, 2, 4, 6, 8]))
+        fma = int(rng.integers(0, 2))
+        three = bool(rng.integers(0, 2))
+        nsw = int(rng.integers(1, 41))
+        CL, CR = float(rng.uniform(-1, 1)), float(rng.uniform(-1, 2))
+        flav = "fma" if fma else None
+        if three:
+            Ds, Df, Dg = 0.0, float(rng.uniform(0.5, 2)), float(rng.uniform(5, 500))
+        else:
+            Ds, Df, Dg = float(10 ** rng.uniform(-4, 0)), float(rng.uniform(0.5, 2)), 0.0
+        imgs, refs = [], []
+        for _ in range(nimg):
+            if three:
+                pix = rng.choice(np.array([0, 120, 255], dtype=np.uint8), size=(ny, nx), p=[0.3, 0.4, 0.3])
+                D = oracle.fill_D_3phase(pix, Df, Ds, Dg)
+                grid, _ = oracle.floodfill((pix > 200).astype(np.uint32))
+                with np.errstate(all="ignore"):
+                    A, b = oracle.discretize(D, CL, CR, grid=grid)
+            else:
+                pix = rand_mask(rng, nx, ny, float(rng.uniform(0.2, 0.8)))
+                D = oracle.fill_D_2phase(pix, Df, Ds)
+                A, b = oracle.discretize(D, CL, CR)
+                grid = None
+            imgs.append((pix, grid))
+            with np.errstate(all="ignore"):
+                refs.append(oracle.sweeps(A, b, oracle.linear_guess(nx, ny, CL, CR, flavour=flav), nsw, flavour=flav))
+        tag = f"case {case}: {nx}x{ny} x{nimg} {kernel} T={T} fma={fma} {'3' if three else '2'}-phase {nsw} sweeps"
+        with pkg.Solver(nx, ny, kernel=kernel, nimg=nimg) as s:
+            s.set_tuning("fma", fma)
+            if T:
+                s.set_tuning("tb_T", T)
+            s.set_image(np.concatenate([p for p, _ in imgs]))
+            if three:
+                s.assemble_3phase(Ds, Df, Dg, CL, CR, grid=np.concatenate([g for _, g in imgs]))
+            else:
+                s.assemble_2phase(Ds, Df, CL, CR)
+            s.init_linear(CL, CR)
+            s.sweeps(nsw)
+            got = s.get_field()
+        for k in range(nimg):
+            a, w = got[k * ny:(k + 1) * ny], refs[k]
+            assert a.shape == w.shape, tag
+            same = (a == w) | (np.isnan(a) & np.isnan(w))
+            assert same.all(), f"{tag}: image {k}, {np.count_nonzero(~same)} cells differ"
+
+
 # ---- contracted arithmetic (opt-in): the oracle's "fma" build is the checker ------------------
 
 @pytest.mark.parametrize("kernel,nx,ny", [("explicit", 96, 64), ("scalar", 97, 41), ("matfree", 96, 64),
