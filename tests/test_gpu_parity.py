@@ -757,6 +757,46 @@ def test_random_small_cases_all_paths(pkg, oracle):
             assert same.all(), f"{tag}: image {k}, {np.count_nonzero(~same)} cells differ"
 
 
+def test_random_stopping_rules_batch_and_stream(pkg, oracle):
+    """80 seeded random solves: check interval, MaxIter and tolerance drawn at random (including the
+    degenerate ones: tolerance above 100 = no sweep, MaxIter below the first check interval, checks
+    every sweep), one image / a stack / a stream through 1-3 slots; every image's sweep count, Deff,
+    conv and field equal the oracle's one-image loop."""
+    rng = np.random.default_rng(777)
+    for case in range(80):
+        nx, ny = int(rng.integers(8, 81)), int(rng.integers(8, 61))
+        nimg = int(rng.integers(1, 5))
+        check_every = int(rng.choice([1, 2, 3, 10, 37, 50]))
+        max_iter = int(rng.integers(1, 301))
+        tol = float(rng.choice([0.0, 1e-2, 1e-3, 1e-5, 150.0]))
+        Ds = float(10 ** rng.uniform(-3, 0))
+        CL, CR = 0.0, float(rng.uniform(0.5, 2))
+        imgs = [rand_mask(rng, nx, ny, float(rng.uniform(0.3, 0.7))) for _ in range(nimg)]
+        want = []
+        for pix in imgs:
+            D = oracle.fill_D_2phase(pix, 1.0, Ds)
+            A, b = oracle.discretize(D, CL, CR)
+            want.append(oracle.jacobi(A, b, oracle.linear_guess(nx, ny, CL, CR), D, CL, CR, tol, max_iter,
+                                      check_every=check_every))
+        tag = f"case {case}: {nx}x{ny} x{nimg} C={check_every} max={max_iter} tol={tol}"
+        with pkg.Solver(nx, ny, nimg=nimg) as s:
+            s.set_image(np.concatenate(imgs))
+            s.assemble_2phase(Ds, 1.0, CL, CR)
+            s.init_linear(CL, CR)
+            res = s.solve(tol, max_iter, check_every=check_every)
+            res = [res] if nimg == 1 else res
+            x = s.get_field()
+            for k, (it, deff, conv, xk, _, _) in enumerate(want):
+                assert (res[k].iters, res[k].deff_raw, res[k].conv) == (it, deff, conv), f"{tag}: batch image {k}"
+                assert_field(x[k * ny:(k + 1) * ny], xk)
+        slots = int(rng.integers(1, 4))
+        with pkg.Solver(nx, ny, nimg=slots) as s:
+            got = s.solve_stream(imgs, Ds, 1.0, CL, CR, tol, max_iter, check_every=check_every, want_fields=True)
+            for k, (it, deff, conv, xk, _, _) in enumerate(want):
+                assert (got[k].iters, got[k].deff_raw, got[k].conv) == (it, deff, conv), f"{tag}: stream image {k} of {slots} slots"
+                assert_field(got[k].field, xk)
+
+
 # ---- contracted arithmetic (opt-in): the oracle's "fma" build is the checker ------------------
 
 @pytest.mark.parametrize("kernel,nx,ny", [("explicit", 96, 64), ("scalar", 97, 41), ("matfree", 96, 64),
