@@ -797,6 +797,57 @@ def test_random_stopping_rules_batch_and_stream(pkg, oracle):
                 assert_field(got[k].field, xk)
 
 
+def test_random_row_slabs(pkg, oracle):
+    """50 seeded random slab decompositions (1-5 slabs, odd / even widths, every T, both arithmetics,
+    2 or 3 phases): sweeps and a short solve equal the oracle bit for bit."""
+    rng = np.random.default_rng(4242)
+    for case in range(50):
+        nslabs = int(rng.integers(1, 6))
+        nx, NY = int(rng.integers(2, 300)), int(rng.integers(8 * nslabs, 8 * nslabs + 120))
+        T = int(rng.choice([0, 1, 2, 4, 6, 8]))
+        fma = int(rng.integers(0, 2))
+        three = bool(rng.integers(0, 2))
+        nsw = int(rng.integers(1, 50))
+        flav = "fma" if fma else None
+        if three:
+            pix = rng.choice(np.array([0, 120, 255], dtype=np.uint8), size=(NY, nx), p=[0.3, 0.4, 0.3])
+            D = oracle.fill_D_3phase(pix, 1.0, 0.0, 40.0)
+            grid, _ = oracle.floodfill((pix > 200).astype(np.uint32))
+            with np.errstate(all="ignore"):
+                A, b = oracle.discretize(D, 0.0, 1.0, grid=grid)
+        else:
+            pix = rand_mask(rng, nx, NY, 0.5)
+            D = oracle.fill_D_2phase(pix, 1.0, 1e-2)
+            A, b = oracle.discretize(D, 0.0, 1.0)
+        x0 = oracle.linear_guess(nx, NY, 0.0, 1.0, flavour=flav)
+        with np.errstate(all="ignore"):
+            ref = oracle.sweeps(A, b, x0, nsw, flavour=flav)
+            it, deff, conv, xs, MFL, MFR = oracle.jacobi(A, b, x0, D, 0.0, 1.0, 1e-3, 150, check_every=20, flavour=flav)
+        tag = f"case {case}: {nx}x{NY} in {nslabs} slabs T={T} fma={fma} {'3' if three else '2'}-phase"
+        with pkg.SlabGroup(nx, NY, [0] * nslabs) as g:
+            g.set_tuning("fma", fma)
+            if T:
+                g.set_tuning("tb_T", T)
+            g.set_image(pix)
+            for _ in range(2):                       # sweeps, then a solve from a fresh guess
+                if three:
+                    g.assemble_3phase(0.0, 1.0, 40.0, 0.0, 1.0, grid=grid)
+                else:
+                    g.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+                g.init_linear(0.0, 1.0)
+                if _ == 0:
+                    g.sweeps(nsw)
+                    a = g.get_field()
+                    same = (a == ref) | (np.isnan(a) & np.isnan(ref))
+                    assert same.all(), f"{tag}: {np.count_nonzero(~same)} cells differ after {nsw} sweeps"
+                else:
+                    r = g.solve(1e-3, 150, check_every=20)
+                    assert (r.iters, r.deff_raw, r.conv) == (it, deff, conv), tag
+                    assert np.array_equal(r.MFL, MFL) and np.array_equal(r.MFR, MFR), tag
+                    a = g.get_field()
+                    assert ((a == xs) | (np.isnan(a) & np.isnan(xs))).all(), tag
+
+
 # ---- contracted arithmetic (opt-in): the oracle's "fma" build is the checker ------------------
 
 @pytest.mark.parametrize("kernel,nx,ny", [("explicit", 96, 64), ("scalar", 97, 41), ("matfree", 96, 64),
