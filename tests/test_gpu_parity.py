@@ -1248,6 +1248,54 @@ def test_extreme_contrasts_and_boundary_values(pkg, oracle, Ds, Df, CL, CR):
             assert_field(s.get_field(), x)
 
 
+def test_abi_misuse_returns_codes_not_crashes(pkg):
+    """Raw C ABI with NULL pointers, bad sizes and wrong call order: a negative code and a message
+    every time, never a crash, and the context stays usable."""
+    import ctypes as C
+    from effectivediffusivityfvm_amd import _capi
+    L = _capi.load()
+    ctx = C.c_void_p()
+    bad = []
+
+    def expect_fail(rc, what):
+        if rc >= 0 or not L.deff_last_error():
+            bad.append(what)
+
+    expect_fail(L.deff_create(0, 1, 8, C.byref(ctx)), "nx = 1")
+    expect_fail(L.deff_create(0, 8, 8, None), "out = NULL")
+    expect_fail(L.deff_create(99, 8, 8, C.byref(ctx)), "device 99")
+    expect_fail(L.deff_create_batch(0, 8, 8, 0, C.byref(ctx)), "nimg = 0")
+    expect_fail(L.deff_create_batch(0, 65536, 65536, 1, C.byref(ctx)), "2^32 cells")
+    assert L.deff_create(0, 24, 16, C.byref(ctx)) == 0
+    res = _capi.Result()
+    expect_fail(L.deff_solve(ctx, 2 / 3, 1e-3, 10, 10, C.byref(res), None, None), "solve before anything")
+    expect_fail(L.deff_assemble_2phase(ctx, 1e-3, 1.0, 0.0, 1.0), "assemble without image")
+    expect_fail(L.deff_set_tuning(ctx, b"no_such_key", 1), "unknown tuning key")
+    expect_fail(L.deff_set_tuning(ctx, b"tb_T", -1), "negative tuning value")
+    expect_fail(L.deff_set_kernel(ctx, 77), "unknown kernel id")
+    v = C.c_int()
+    expect_fail(L.deff_get_plan(ctx, b"nope", C.byref(v)), "unknown plan key")
+    pix = np.zeros((16, 24), dtype=np.uint8)
+    expect_fail(L.deff_set_image(ctx, pix, 24, 16, 2, 1), "amplification does not match the mesh")
+    expect_fail(L.deff_set_image(ctx, pix, 0, 16, 1, 1), "W = 0")
+    assert L.deff_set_image(ctx, pix, 24, 16, 1, 1) == 0
+    assert L.deff_assemble_2phase(ctx, 1e-3, 1.0, 0.0, 1.0) == 0
+    expect_fail(L.deff_sweeps(ctx, 3, 2 / 3, None), "sweeps without a field")
+    assert L.deff_init_linear(ctx, 0.0, 1.0) == 0
+    expect_fail(L.deff_sweeps(ctx, -1, 2 / 3, None), "negative sweep count")
+    expect_fail(L.deff_solve(ctx, 2 / 3, 1e-3, 10, 0, C.byref(res), None, None), "check_every = 0")
+    expect_fail(L.deff_solve(ctx, 2 / 3, 1e-3, 10, 10, None, None, None), "result = NULL")
+    grp = C.c_void_p()
+    expect_fail(L.deff_slab_group_create(4, None, 64, 20, C.byref(grp)), "5 rows per slab")
+    expect_fail(L.deff_slab_group_create(0, None, 64, 64, C.byref(grp)), "0 slabs")
+    expect_fail(L.deff_slab_rank_create(0, 64, 64, 3, 2, b"x" * 128, C.byref(grp)), "rank >= nranks")
+    # and after all that the context still works
+    assert L.deff_solve(ctx, 2 / 3, 1e-3, 50, 10, C.byref(res), None, None) == 0 and res.iters > 0
+    assert L.deff_destroy(ctx) == 0
+    assert L.deff_destroy(None) == 0
+    assert not bad, bad
+
+
 def test_errors_are_loud(pkg):
     with pkg.Solver(16, 16) as s:
         with pytest.raises(pkg.DeffError):
