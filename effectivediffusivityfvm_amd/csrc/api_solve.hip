@@ -65,8 +65,10 @@ static void tile_grid(const deff_ctx *c, int cols_per_block, int rows, SweepPlan
 
 int default_tb_T(const deff_ctx *c)
 {
-    if (c->n < ((size_t)1 << 22)) return 4;
-    return (c->nimg == 1 && !c->slab && c->n >= ((size_t)1 << 24)) ? 8 : 6;
+    // below 4 Mi cells the launch is latency-bound and T = 4 wins; above, T = 8 everywhere (with the
+    // prefetch really in flight, kernels_tb.hpp, stacks no longer prefer T = 6: 1 024 x 128^2 1 222 vs
+    // 1 125 G cells*iter/s, 64 x 1024^2 1 258 vs 1 156, 16 x 1024^2 1 106 vs 1 064)
+    return c->n < ((size_t)1 << 22) ? 4 : 8;
 }
 
 // Harvest the row dictionary of the explicit system (kernels_dict.hpp).  On success the context

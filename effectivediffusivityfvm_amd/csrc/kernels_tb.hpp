@@ -32,6 +32,9 @@
 
 namespace deff {
 
+#ifndef TB_TOUCH_PH
+#define TB_TOUCH_PH 2
+#endif
 constexpr int TB_COLS = 128;                                   // columns per wave strip (2 per lane)
 template <bool V> struct TbTag { static constexpr bool value = V; };   // compile-time flag for generic lambdas
 
@@ -162,8 +165,14 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
         const int rr = r_begin + k;
         const bool ok = in_x && rr >= row_lo && rr < row_hi && rr < r_end;
         const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col : 0);
-        nx_x[k] = ok ? ld2(x + p) : zero;
-        nx_c[k] = ok ? *reinterpret_cast<const uint32_t *>(code + p) : 0u;   // rows / lanes outside the mesh: zero row
+        // the loads are issued UNCONDITIONALLY (the address is clamped into the array) and the value is
+        // selected afterwards: with `ok ? load : 0` hipcc branches around the loads, no longer knows how
+        // many are in flight, and waits with vmcnt(0) right after issuing the next group's loads --
+        // i.e. no prefetch at all (found by removing the loads / the store: +23 % / +30 %)
+        const double2 vx = ld2(x + p);
+        const unsigned vc = *reinterpret_cast<const uint32_t *>(code + p);
+        nx_x[k] = ok ? vx : zero;
+        nx_c[k] = ok ? vc : 0u;                                              // rows / lanes outside the mesh: zero row
     }
 
     // (Measured with the tile time stamps, tools/tb_stamps.py: waves sharing a SIMD are served
@@ -191,8 +200,10 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
             const int rr = r + 3 + k;
             const bool ok = in_x && rr >= row_lo && rr < row_hi && rr < r_end;
             const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col : 0);
-            nx_x[k] = ok ? ld2(x + p) : zero;
-            nx_c[k] = ok ? *reinterpret_cast<const uint32_t *>(code + p) : 0u;   // rows / lanes outside the mesh: zero row
+            const double2 vx = ld2(x + p);                                   // unconditional, see above
+            const unsigned vc = *reinterpret_cast<const uint32_t *>(code + p);
+            nx_x[k] = ok ? vx : zero;
+            nx_c[k] = ok ? vc : 0u;                                          // rows / lanes outside the mesh: zero row
         }
 #pragma unroll
         for (int ph = 0; ph < 3; ++ph) {
@@ -219,6 +230,16 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
                 double2 o;
                 o.x = tb_cell<GUARD, WALL, FMA>(lut, o0, vC.x, xw0, vC.y, vS.x, vN.x, omw);
                 o.y = tb_cell<GUARD, WALL, FMA>(lut, o1, vC.y, vC.x, xe1, vS.y, vN.y, omw);
+                if (t == T && ph == TB_TOUCH_PH) {
+                    // CDNA counts loads and stores in one vmcnt and lets stores complete out of order, so
+                    // "the prefetched rows have arrived" can only be expressed as vmcnt(0), which also
+                    // waits for every store in flight.  Ask for the prefetched group HERE, before the
+                    // group's last store goes out: the two stores then in flight are a step old (acked),
+                    // whereas at the top of the next group the wait would sit right behind a fresh store
+                    // (measured by deleting the store: +21..30 %).
+                    asm volatile("" :: "v"(nx_x[0].x), "v"(nx_x[0].y), "v"(nx_x[1].x), "v"(nx_x[1].y), "v"(nx_x[2].x),
+                                 "v"(nx_x[2].y), "v"(nx_c[0]), "v"(nx_c[1]), "v"(nx_c[2]));
+                }
                 if (t < T) {
                     w[t][sS] = o;
                 } else if (st_x && rt >= ry0 && rt < ry1) {
