@@ -107,6 +107,58 @@ __global__ __launch_bounds__(256) void k_banks(double *out, int iters)
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// One sweep level of the temporally blocked kernel, in isolation: per lane two cells, each
+//   sigma = aW*xw; sigma += aE*xe; sigma += aS*xs; sigma += aN*xn; o = omw*xc + c0*(0 - sigma)
+// (11 FP64 instructions, one dependent chain per cell) + 4 DPP moves for the W/E neighbours, no
+// global memory.  LUT = 0: coefficients in registers; LUT = 1: the 10 coefficients come from LDS by
+// per-lane row offsets that change every level (32 rows, conflict-free like the commonest rows of
+// the dictionary).  8 levels per iteration, each level feeding the next like the register pipeline.
+template <int LUT>
+__global__ __launch_bounds__(256) void k_level(double *out, int iters, double omw)
+{
+    __shared__ double tab[6 * 520];
+    for (int i = threadIdx.x; i < 6 * 520; i += 256) tab[i] = 1.0 / (1.0 + (i % 97));
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    unsigned cw = (unsigned)(lane * 2654435761u);
+    double2 vN = make_double2(0.3 + lane, 0.7), vC = make_double2(0.5, 0.25 + lane), vS = make_double2(0.1, 0.9);
+    const double c0r = 0.61, aWr = -0.21, aEr = -0.23, aSr = -0.27, aNr = -0.29;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            int lo = __double2loint(vC.y), hi = __double2hiint(vC.y);
+            lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
+            hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+            const double xw0 = __hiloint2double(hi, lo);
+            lo = __double2loint(vC.x); hi = __double2hiint(vC.x);
+            lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);
+            hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+            const double xe1 = __hiloint2double(hi, lo);
+            double c00 = c0r, aW0 = aWr, aE0 = aEr, aS0 = aSr, aN0 = aNr, c01 = c0r, aW1 = aWr, aE1 = aEr, aS1 = aSr, aN1 = aNr;
+            if (LUT) {
+                cw = cw * 1664525u + 1013904223u;
+                const unsigned off0 = ((cw >> 8) & 31u) * 8u, off1 = ((cw >> 20) & 31u) * 8u;
+                const char *b0 = reinterpret_cast<const char *>(tab) + off0, *b1 = reinterpret_cast<const char *>(tab) + off1;
+                c00 = *reinterpret_cast<const double *>(b0);            c01 = *reinterpret_cast<const double *>(b1);
+                aW0 = *reinterpret_cast<const double *>(b0 + 4160);     aW1 = *reinterpret_cast<const double *>(b1 + 4160);
+                aE0 = *reinterpret_cast<const double *>(b0 + 2 * 4160); aE1 = *reinterpret_cast<const double *>(b1 + 2 * 4160);
+                aS0 = *reinterpret_cast<const double *>(b0 + 3 * 4160); aS1 = *reinterpret_cast<const double *>(b1 + 3 * 4160);
+                aN0 = *reinterpret_cast<const double *>(b0 + 4 * 4160); aN1 = *reinterpret_cast<const double *>(b1 + 4 * 4160);
+            }
+            double s0 = aW0 * xw0, s1 = aW1 * vC.x;
+            s0 += aE0 * vC.y; s1 += aE1 * xe1;
+            s0 += aS0 * vS.x; s1 += aS1 * vS.y;
+            s0 += aN0 * vN.x; s1 += aN1 * vN.y;
+            double2 o;
+            o.x = omw * vC.x + c00 * (0.0 - s0);
+            o.y = omw * vC.y + c01 * (0.0 - s1);
+            vN = vC; vC = vS; vS = o;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = vS.x + vS.y + vC.x + vN.y + (double)cw;
+}
+
 template <class F>
 static double time_ms(F launch)
 {
@@ -133,7 +185,7 @@ int main()
     double *out;
     CHECK(hipMalloc(&out, sizeof(double) * 256 * cus * 8));
     const int iters = 20000;
-    for (int wg_per_cu : {1, 2, 4}) {                       // 4 / 8 / 16 waves per CU = 1 / 2 / 4 per SIMD
+    for (int wg_per_cu : {1, 2, 3, 4}) {                       // 4 / 8 / 16 waves per CU = 1 / 2 / 4 per SIMD
         const int blocks = cus * wg_per_cu;
         const double waves_per_simd = wg_per_cu;            // 256 threads = 4 waves = 1 per SIMD
         auto report = [&](const char *name, double ms, double instr_per_iter) {
@@ -150,6 +202,8 @@ int main()
         report("v_mul_f64 2 VGPR sources, same banks", time_ms([&] { hipLaunchKernelGGL((k_banks<1, 0>), dim3(blocks), dim3(256), 0, 0, out, iters * 4); }), 32);
         report("v_fma_f64 3 VGPR sources, 2 banks", time_ms([&] { hipLaunchKernelGGL((k_banks<0, 1>), dim3(blocks), dim3(256), 0, 0, out, iters * 4); }), 32);
         report("v_fma_f64 3 VGPR sources, same banks", time_ms([&] { hipLaunchKernelGGL((k_banks<1, 1>), dim3(blocks), dim3(256), 0, 0, out, iters * 4); }), 32);
+        report("TB sweep level, coefficients in registers (clocks per level)", time_ms([&] { hipLaunchKernelGGL(k_level<0>, dim3(blocks), dim3(256), 0, 0, out, iters / 4, 1.0 / 3.0); }), 2);
+        report("TB sweep level, 10 LDS lookups          (clocks per level)", time_ms([&] { hipLaunchKernelGGL(k_level<1>, dim3(blocks), dim3(256), 0, 0, out, iters / 4, 1.0 / 3.0); }), 2);
         report("v_mov_b32_dpp wave_shr/shl", time_ms([&] { hipLaunchKernelGGL(k_dpp, dim3(blocks), dim3(256), 0, 0, (int *)out, iters); }), 32);
         report("ds_read_b64 consecutive", time_ms([&] { hipLaunchKernelGGL(k_lds<0>, dim3(blocks), dim3(256), 0, 0, out, iters); }), 32);
         report("ds_read_b64 random rows", time_ms([&] { hipLaunchKernelGGL(k_lds<1>, dim3(blocks), dim3(256), 0, 0, out, iters); }), 32);
