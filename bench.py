@@ -10,12 +10,22 @@ already resident in HBM.  With N > 1 every rank solves its own image (image
 index = rank): the path shards as whole images, there is no data-path
 collective, scaling is weak.  Rank 0 prints ONE JSON line.
 
-roofline: algorithmic bytes = 64 B per cell per sweep (A 5x8 + b 8 + x 8 read,
-xNew 8 written: the operator behind the reference's seam) x
-cells x sweeps per launch, divided by the sweep kernel's average launch duration
-measured with HIP events on the solver's own stream inside deff_sweeps().
-cpu_baseline: the single-thread CPU oracle on a bounded sample of the same
-workload (rank 0, N = 1 only); a reported baseline, not the target.
+roofline (always a fraction of a real roof, <= 1 by construction):
+  * the default kernel (temporally blocked, matrix-free) never moves the explicit operator's 64 B per
+    cell per sweep and is bound by FP64 issue, so its block says bound = "fp64_valu": algorithmic flops
+    = 11 FP64 add/mul per cell per sweep (7 fused in contracted arithmetic) x cells x sweeps per launch
+    / the kernel's average launch duration (HIP events on the solver's own stream inside
+    deff_sweeps()), against 39.3 TFLOP/s = one FP64 VALU instruction per lane per 4 clocks x 1024
+    SIMDs x 2.4 GHz (the 78.6 TFLOP/s FP64 vector peak counts an FMA as two; the reference's
+    written operation order has none).  Its own HBM model (x 8 + code 2 read, xNew 8 written = 18 B per
+    cell per LAUNCH) is reported beside it (`hbm_own_model`).
+  * the contract figure of SURVEY.md 8d -- 64 B per cell per sweep (A 5x8 + b 8 + x 8 read, xNew 8
+    written: the operator behind the reference's seam) -- is measured on the explicit-coefficient
+    kernel in the same run and sits in the same block: roofline.contract_64B_frac (+ _kernel,
+    _launch_us, _achieved_GBs).  With --kernel explicit it IS the top-level bound ("hbm").
+cpu_baseline: the single-thread CPU oracle on a bounded sample of the same workload (rank 0, N = 1
+only); a reported baseline, not the target.  The field it produces is kept and the GPU field after
+the same number of sweeps from the same start must be array_equal to it: "parity_checked".
 """
 import argparse
 import json
@@ -27,11 +37,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-BYTES_PER_CELL_SWEEP = 64.0
+BYTES_PER_CELL_SWEEP = 64.0      # the explicit operator behind the reference seam
+OWN_BYTES_PER_CELL_LAUNCH = 18.0  # matrix-free kernels: x 8 + code 2 read, xNew 8 written, per LAUNCH
+# FP64 VALU: a wave64 v_add/v_mul/v_fma_f64 occupies its SIMD for 4 clocks (16 lanes/clk; tools/ubench measures 4.4)
+# -> 1024 SIMDs x 16 x 2.4 GHz = 39.3 T instructions-lanes/s; an FMA counts 2 flops (78.6 TFLOP/s vector peak)
+FP64_INSTR_PEAK_T = 39.3216
+FP64_INSTR_PER_CELL = {False: 11, True: 7}   # tb_cell(): default arithmetic / contracted (kernels_tb.hpp)
 
 
 def cpu_baseline(n, seconds_target=12.0):
-    """Single-thread oracle sweep rate on the same synthetic workload (bounded sample)."""
+    """Single-thread oracle sweep rate on the same synthetic workload (bounded sample).
+    Returns (block, sweeps, field): the field after `sweeps` sweeps from the linear guess is kept so that
+    the GPU path can be checked against it (parity_checked)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     ob.build()
@@ -44,11 +61,11 @@ def cpu_baseline(n, seconds_target=12.0):
     per = (time.perf_counter() - t0) / 2
     k = max(2, min(2000, int(seconds_target / max(per, 1e-9))))
     t0 = time.perf_counter()
-    ob.sweeps(A, b, x, k)
+    x = ob.sweeps(A, b, x, k)
     dt = time.perf_counter() - t0
-    return {"value": n * n * k / dt / 1e6, "unit": "Mcells*iter/s", "cores": 1, "kind": "port",
-            "sample": f"{k} sweeps of the {n}x{n} synthetic image, oracle/deff_oracle.c (gcc -O2, AoS, 1 thread), "
-                      f"host has {os.cpu_count()} logical CPUs"}
+    return ({"value": n * n * k / dt / 1e6, "unit": "Mcells*iter/s", "cores": 1, "kind": "port",
+             "sample": f"{k} sweeps of the {n}x{n} synthetic image, oracle/deff_oracle.c (gcc -O2, AoS, 1 thread), "
+                       f"host has {os.cpu_count()} logical CPUs"}, k + 2, x)
 
 
 def bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier, use_dist):
@@ -165,13 +182,17 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                      # per-rank times: a slow rank must be visible in the line
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        elapsed = max(float(t.item()) for t in every)     # = all_reduce(MAX)
 
     launches, sweeps_per_launch = s.last_launches()     # of the last step
     kernel_used = s.kernel_in_use()
+    plan = s.plan() if kernel_used == "matfree_tb" else None
 
     # Secondary, untimed-by-the-driver leg: the explicit-coefficient kernel, i.e. the
     # operator exactly as it sits behind the reference's seam (A, b streamed: 64 B/cell/sweep).
@@ -203,8 +224,6 @@ def main():
         cells = float(n) * n * args.batch
         total_launches = args.steps * launches
         launch_s = kernel_ms * 1e-3 / total_launches      # avg duration of one sweep-kernel launch (HIP events)
-        alg_bytes = BYTES_PER_CELL_SWEEP * cells * sweeps_per_launch
-        achieved = alg_bytes / launch_s / 1e9
 
         def traffic_of(kname):
             tfile = os.path.join(ROOT, "profiles", "traffic.json")
@@ -212,6 +231,56 @@ def main():
                 return json.load(open(tfile)).get(f"{kname}_{n}")
             except Exception:
                 return None
+
+        if kernel_used in ("matfree", "matfree_tb"):
+            own = OWN_BYTES_PER_CELL_LAUNCH * cells
+            own_block = {"bound": "hbm", "bytes_per_launch": own, "achieved": own / launch_s / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": own / launch_s / 1e9 / HBM_PEAK_GBS,
+                         "model": "x 8 + row code 2 read, xNew 8 written = 18 B per cell per LAUNCH (the coefficients "
+                                  "come from a 16-bit code through the row dictionary in LDS, never from HBM)"}
+        if kernel_used == "matfree_tb":
+            ipc = FP64_INSTR_PER_CELL[False]
+            flops = ipc * cells * sweeps_per_launch
+            ach = flops / launch_s / 1e12
+            roofline = {
+                "bound": "fp64_valu", "achieved": ach, "peak": FP64_INSTR_PEAK_T, "unit": "TFLOP/s",
+                "frac": ach / FP64_INSTR_PEAK_T, "traffic": None, "kernel": kernel_used,
+                "launch_us": launch_s * 1e6, "sweeps_per_launch": sweeps_per_launch,
+                "algorithmic_flops_per_launch": flops,
+                "model": f"{ipc} FP64 add/mul per cell per sweep (reference operation order, no FMA: kernels_tb.hpp tb_cell) x "
+                         f"cells x {sweeps_per_launch} sweeps per launch; peak = one FP64 VALU instruction per lane per 4 "
+                         "clocks x 1024 SIMDs x 2.4 GHz = 39.3 T/s (half the 78.6 TFLOP/s FMA-counted vector peak); "
+                         "recomputed halo cells are NOT counted",
+                "hbm_own_model": own_block,
+            }
+        elif kernel_used == "matfree":
+            roofline = dict(own_block, traffic=None, kernel=kernel_used, launch_us=launch_s * 1e6)
+        else:
+            alg_bytes = BYTES_PER_CELL_SWEEP * cells * sweeps_per_launch
+            ach = alg_bytes / launch_s / 1e9
+            roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": kernel_used,
+                        "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
+                        "model": "64 B per cell per sweep (A 40 + b 8 + x 8 read, xNew 8 written: the explicit "
+                                 "operator behind the reference seam, SURVEY.md 8d)",
+                        "contract_64B_frac": ach / HBM_PEAK_GBS, "contract_64B_kernel": kernel_used,
+                        "contract_64B_launch_us": launch_s * 1e6, "contract_64B_achieved_GBs": ach}
+        tr = traffic_of(kernel_used)
+        if tr:
+            roofline["traffic"] = tr["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = tr.get("source")
+        if explicit:
+            el, ek = explicit
+            ea = BYTES_PER_CELL_SWEEP * cells / el / 1e9
+            # the contract figure (64 B per cell per sweep) on the explicit operator, same run
+            roofline["contract_64B_frac"] = ea / HBM_PEAK_GBS
+            roofline["contract_64B_kernel"] = ek
+            roofline["contract_64B_launch_us"] = el * 1e6
+            roofline["contract_64B_achieved_GBs"] = ea
+            roofline["contract_64B_Mcells_iter_per_s"] = cells / el / 1e6
+            tre = traffic_of(ek)
+            if tre:
+                roofline["contract_64B_traffic"] = tre["hbm_bytes_per_launch"]
 
         out = {
             "metric": "Mcells*iter/s (Jacobi sweep) at 4096^2" if n == 4096 else f"Mcells*iter/s (Jacobi sweep) at {n}^2",
@@ -235,36 +304,11 @@ def main():
                 "sweeps_per_launch": sweeps_per_launch,
                 "deff_raw_after_run": deff,
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "kernel": kernel_used,
-                "launch_us": launch_s * 1e6,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "model": "64 B per cell per sweep (A 40 + b 8 + x 8 read, xNew 8 written: the explicit operator "
-                         "behind the reference seam, SURVEY.md 8d) x cells x sweeps per launch",
-            },
+            "roofline": roofline,
+            "per_rank_ms_per_step": per_rank_ms,
         }
-        if kernel_used in ("matfree", "matfree_tb"):
-            # this kernel never materialises A: its own compulsory traffic is x 8 + code 2 read, xNew 8
-            # written per cell per LAUNCH (a temporally blocked launch does sweeps_per_launch sweeps on it)
-            own = 18.0 * cells
-            if kernel_used == "matfree_tb":
-                out["roofline"]["limiter"] = ("not HBM: FP64 issue ~50-55 % busy (an FP64 instruction issues once per "
-                                              "8 clocks from one wave, the 4-clock rate needs two ready waves per SIMD; "
-                                              "3-4 fit the registers), LDS row lookups ~40 %; profiles/r01d_tb_sq_counters.json, "
-                                              "tools/ubench")
-            out["roofline"]["own_model"] = {
-                "bytes_per_launch": own,
-                "achieved": own / launch_s / 1e9,
-                "frac": own / launch_s / 1e9 / HBM_PEAK_GBS,
-                "note": "matrix-free: coefficients come from a 16-bit row code through an LDS row dictionary; frac of the "
-                        "64-B model above can exceed 1 because those bytes are never moved",
-            }
+        if plan:
+            out["config"]["plan"] = plan
         if omega1_ms:
             out["jacobi_omega_1"] = {"value": cells * S / (omega1_ms * 1e-3) / 1e6, "unit": "Mcells*iter/s",
                                      "sample": f"{S} sweeps with omega = 1 (plain Jacobi, updateX_V1), same image, one GPU"}
@@ -273,30 +317,33 @@ def main():
                 "value": cells * S / (fma_ms * 1e-3) / 1e6, "unit": "Mcells*iter/s",
                 "sample": f"{S} sweeps with deff_set_tuning('fma', 1): sigma += a*x as fma, final sum as fma "
                           "(7 instead of 11 FP64 instructions per cell); parity: bit-identical to the oracle built "
-                          "with -ffp-contract=fast, reproduces the survey's primary recorded Deff for config #1"}
-        tr = traffic_of(kernel_used)
-        if tr:
-            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = tr.get("source")
-        if explicit:
-            el, ek = explicit
-            ea = BYTES_PER_CELL_SWEEP * cells / el / 1e9
-            out["explicit_operator"] = {
-                "kernel": ek,
-                "value": cells / el / 1e6,
-                "unit": "Mcells*iter/s",
-                "sample": f"{args.explicit_sweeps} sweeps, same image, same run",
-                "roofline": {"bound": "hbm", "achieved": ea, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": ea / HBM_PEAK_GBS, "launch_us": el * 1e6,
-                             "algorithmic_bytes_per_launch": BYTES_PER_CELL_SWEEP * cells, "traffic": None},
-            }
-            tr = traffic_of(ek)
-            if tr:
-                out["explicit_operator"]["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-                out["explicit_operator"]["roofline"]["traffic_source"] = tr.get("source")
+                          "with -ffp-contract=fast"}
+            if kernel_used == "matfree_tb":
+                fl = FP64_INSTR_PER_CELL[True] * cells * S / (fma_ms * 1e-3) / 1e12
+                out["contracted_arithmetic"]["fp64_instr_frac"] = fl / FP64_INSTR_PEAK_T
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n)
-        print(json.dumps(out), flush=True)
+            base, K, want = cpu_baseline(n)
+            out["cpu_baseline"] = base
+            if args.batch != 1:
+                print(json.dumps(out), flush=True)
+                s.close()
+                return
+            # parity, where the money is: the SAME K sweeps from the same start (linear guess) on the GPU, on the
+            # kernel that was just timed, must give the oracle's field bit for bit (north-star bar: 1e-6 rel L2)
+            import numpy as np
+            s.init_linear(0.0, 1.0)
+            s.sweeps(K, 2.0 / 3.0)
+            got = s.get_field()
+            rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+            equal = bool(np.array_equal(got, want))
+            out["parity_checked"] = equal
+            out["parity_sweeps"] = K
+            out["parity_rel_l2"] = rel
+            out["parity_kernel"] = s.kernel_in_use()
+            print(json.dumps(out), flush=True)
+            assert equal and rel <= 1e-6, f"GPU field after {K} sweeps differs from the oracle's (rel L2 {rel:.3e})"
+        else:
+            print(json.dumps(out), flush=True)
     s.close()
     if use_dist:
         dist.destroy_process_group()

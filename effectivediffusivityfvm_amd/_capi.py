@@ -22,7 +22,7 @@ SYMBOLS = [
     "deff_set_tuning", "deff_get_plan", "deff_set_image", "deff_synth_image", "deff_get_image",
     "deff_load_jpeg_gray", "deff_free", "deff_assemble_2phase", "deff_assemble_3phase", "deff_flood_fill", "deff_assemble_from_D", "deff_set_system", "deff_get_system",
     "deff_init_linear", "deff_set_field", "deff_get_field", "deff_solve", "deff_solve_batch", "deff_sweeps",
-    "deff_slab_group_create", "deff_slab_group_destroy", "deff_slab_group_layout", "deff_slab_group_set_tuning",
+    "deff_slab_group_create", "deff_slab_group_destroy", "deff_slab_group_layout", "deff_slab_group_set_tuning", "deff_slab_group_get_plan",
     "deff_slab_group_set_image", "deff_slab_group_synth_image", "deff_slab_group_assemble_2phase",
     "deff_slab_group_init_linear", "deff_slab_group_set_field", "deff_slab_group_get_field",
     "deff_slab_group_sweeps", "deff_slab_group_flux", "deff_slab_group_solve",
@@ -112,6 +112,7 @@ def load():
     L.deff_slab_group_destroy.argtypes = [ctx]
     L.deff_slab_group_layout.argtypes = [ctx, ip, ip]
     L.deff_slab_group_set_tuning.argtypes = [ctx, C.c_char_p, C.c_int]
+    L.deff_slab_group_get_plan.argtypes = [ctx, C.c_int, C.c_char_p, C.POINTER(C.c_int)]
     L.deff_slab_group_set_image.argtypes = [ctx, _u8p]
     L.deff_slab_group_synth_image.argtypes = [ctx, C.c_uint64, C.c_uint64]
     L.deff_slab_group_assemble_2phase.argtypes = [ctx, C.c_double, C.c_double, C.c_double, C.c_double]
@@ -145,10 +146,6 @@ def load():
     L.deff_debug_tb_stamps.argtypes = [ctx, C.c_double, C.c_void_p, C.POINTER(C.c_int)]
     L.deff_device_field.argtypes = [ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.deff_synchronize.argtypes = [ctx]
-    for name in SYMBOLS:
-        fn = getattr(L, name)
-        if fn.restype is C.c_int:
-            pass
     _lib = L
     return L
 

@@ -378,6 +378,7 @@ int explicit_from_image(deff_ctx *c)
     HIP_TRY(hipGetLastError());
     c->have_explicit = true;
     c->c0_omega = NAN;
+    c->wrap_links = false;
     return DEFF_OK;
 }
 
@@ -411,7 +412,7 @@ try {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));        // Grid may be freed by the caller
     c->have_explicit = true; c->c0_omega = NAN; c->have_walls = true;
-    c->have_matfree = false; c->dict_tried = false;
+    c->have_matfree = false; c->dict_tried = false; c->wrap_links = false;
     return DEFF_OK;
 }
 DEFF_API_CATCH
@@ -474,7 +475,7 @@ try {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_explicit = true; c->c0_omega = NAN; c->have_walls = true;
-    c->have_matfree = false; c->dict_tried = false;
+    c->have_matfree = false; c->dict_tried = false; c->wrap_links = false;
     return DEFF_OK;
 }
 DEFF_API_CATCH
@@ -484,6 +485,14 @@ extern "C" int deff_set_system(deff_ctx *c, const double *A, const double *b, co
 try {
     if (!c || !A || !b) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
+    // W link of a first-column cell / E link of a last-column cell: never produced by the reference's assembly
+    // (cuh:849-864), but a caller-built A may hold one; see deff_ctx::wrap_links
+    bool wrap = false;
+    for (int i = 0; i < c->rows && !wrap; ++i)
+        wrap = A[((size_t)i * c->nxt) * 5 + 1] != 0 || A[((size_t)(i + 1) * c->nxt - 1) * 5 + 2] != 0;
+    if (wrap && c->nx != c->nxt)
+        return fail(DEFF_EINVAL, "the system links a wall column to the neighbouring row (A[.][1] != 0 in column 0 or A[.][2] != 0 "
+                                 "in the last column): not supported for an odd mesh width (%d)", c->nxt);
     TRY(ensure_explicit(c));
     TRY(ensure_scratch(c, sizeof(double) * 5 * CHUNK_CELLS));
     const size_t n_mesh = (size_t)c->nxt * c->rows;       // cells of the caller's arrays
@@ -519,6 +528,7 @@ try {
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_explicit = true; c->c0_omega = NAN;
     c->have_matfree = false; c->dict_tried = false;
+    c->wrap_links = wrap;
     return DEFF_OK;
 }
 DEFF_API_CATCH

@@ -31,7 +31,7 @@ struct deff_slab_group {
     std::vector<double> mfl, mfr;             // global wall fluxes of the last check
 };
 
-static int slab_create_ctx(int device, int nx, int NY, int g0, int own, deff_ctx **out)
+static int slab_create_ctx(int device, int nx, int NY, int nslabs, int g0, int own, deff_ctx **out)
 {
     const int rows = own + 2 * SLAB_HALO;
     TRY(deff_create_batch(device, nx, rows, 1, out));
@@ -44,6 +44,8 @@ static int slab_create_ctx(int device, int nx, int NY, int g0, int own, deff_ctx
     c->own_h = own;
     c->dy = 1.0 / NY;                         // the mesh is the whole image, cuh:1911
     c->kernel = DEFF_KERNEL_MATFREE_TB;
+    // one T per IMAGE: keyed on the largest slab's array, a function of (nx, NY, nslabs) only
+    c->tb_ref_cells = (size_t)c->nx * (size_t)((NY + nslabs - 1) / nslabs + 2 * SLAB_HALO);
     return DEFF_OK;
 }
 
@@ -61,7 +63,7 @@ try {
     for (int r = 0; r < nslabs && rc == DEFF_OK; ++r) {
         const int a = (int)((long long)NY * r / nslabs), b = (int)((long long)NY * (r + 1) / nslabs);
         deff_ctx *c = nullptr;
-        rc = slab_create_ctx(devices ? devices[r] : 0, nx, NY, a, b - a, &c);
+        rc = slab_create_ctx(devices ? devices[r] : 0, nx, NY, nslabs, a, b - a, &c);
         if (rc != DEFF_OK) break;
         g->ctx.push_back(c); g->g0.push_back(a); g->own.push_back(b - a);
         hipEvent_t ev = nullptr;
@@ -302,6 +304,10 @@ static int slab_plans(deff_slab_group *g, double omega, std::vector<SweepPlan> &
         pl1[r].T_override = 1;
         TRY(plan_sweeps(c, omega, &pl1[r]));
         c->last_launches = 0;
+        // all slabs of one image advance in lock-step: one T, one exchange per pass
+        if (plT[r].T != plT[0].T)
+            return fail(DEFF_ESTATE, "slab %d plans %d sweeps per pass, slab 0 plans %d: set tb_T on the group, not per slab", r,
+                        plT[r].T, plT[0].T);
     }
     return DEFF_OK;
 }
@@ -397,6 +403,13 @@ try {
     if (!g) return fail(DEFF_EINVAL, "group is NULL");
     for (int r = 0; r < g->n; ++r) TRY(deff_set_tuning(g->ctx[r], key, value));
     return DEFF_OK;
+}
+DEFF_API_CATCH
+
+extern "C" int deff_slab_group_get_plan(deff_slab_group *g, int slab, const char *key, int *value)
+try {
+    if (!g || slab < 0 || slab >= g->n) return fail(DEFF_EINVAL, "bad slab index");
+    return deff_get_plan(g->ctx[slab], key, value);
 }
 DEFF_API_CATCH
 
@@ -504,7 +517,7 @@ static int slab_rank_create_impl(int device, int nx, int NY, int rank, int nrank
         s->h_recv_up.assign(blk, 0.0); s->h_recv_dn.assign(blk, 0.0);
         s->h_pack.assign((size_t)2 * s->maxown, 0.0);
     }
-    int rc = slab_create_ctx(device, nx, NY, s->g0[rank], s->own[rank], &s->ctx);
+    int rc = slab_create_ctx(device, nx, NY, nranks, s->g0[rank], s->own[rank], &s->ctx);
     if (rc == DEFF_OK) {
         ncclUniqueId id;
         if (id128) memcpy(&id, id128, sizeof id);
@@ -642,17 +655,24 @@ static int rank_exchange(deff_slab_rank *s)
         HIP_TRY(hipStreamSynchronize(c->stream));                // the host buffers are reused by the next pass
         return DEFF_OK;
     }
+    // a failure between GroupStart and GroupEnd must still close the group, or every later collective
+    // on this communicator is poisoned: remember the first error, always call ncclGroupEnd, then report
     NCCL_TRY(ncclGroupStart());
+    ncclResult_t first = ncclSuccess;
+    const char *what = "";
+    auto step = [&](ncclResult_t r, const char *name) { if (first == ncclSuccess && r != ncclSuccess) { first = r; what = name; } };
     if (s->rank > 0) {
-        NCCL_TRY(ncclSend(x + (size_t)c->own_lo * s->nx, blk, ncclDouble, s->rank - 1, s->comm, c->stream));
-        NCCL_TRY(ncclRecv(x, blk, ncclDouble, s->rank - 1, s->comm, c->stream));
+        step(ncclSend(x + (size_t)c->own_lo * s->nx, blk, ncclDouble, s->rank - 1, s->comm, c->stream), "ncclSend(up)");
+        step(ncclRecv(x, blk, ncclDouble, s->rank - 1, s->comm, c->stream), "ncclRecv(up)");
     }
     if (s->rank + 1 < s->nranks) {
-        NCCL_TRY(ncclSend(x + (size_t)(c->own_lo + c->own_h - SLAB_HALO) * s->nx, blk, ncclDouble, s->rank + 1, s->comm,
-                          c->stream));
-        NCCL_TRY(ncclRecv(x + (size_t)(c->own_lo + c->own_h) * s->nx, blk, ncclDouble, s->rank + 1, s->comm, c->stream));
+        step(ncclSend(x + (size_t)(c->own_lo + c->own_h - SLAB_HALO) * s->nx, blk, ncclDouble, s->rank + 1, s->comm, c->stream),
+             "ncclSend(down)");
+        step(ncclRecv(x + (size_t)(c->own_lo + c->own_h) * s->nx, blk, ncclDouble, s->rank + 1, s->comm, c->stream), "ncclRecv(down)");
     }
-    NCCL_TRY(ncclGroupEnd());
+    const ncclResult_t end = ncclGroupEnd();
+    if (first != ncclSuccess) return fail(DEFF_ECOMM, "%s failed: %s", what, ncclGetErrorString(first));
+    if (end != ncclSuccess) return fail(DEFF_ECOMM, "ncclGroupEnd failed: %s", ncclGetErrorString(end));
     return DEFF_OK;
 }
 

@@ -68,8 +68,12 @@ int default_tb_T(const deff_ctx *c)
     // below 4 Mi cells the launch is latency-bound and T = 4 wins; above, T = 8 everywhere (with the
     // prefetch really in flight, kernels_tb.hpp, stacks no longer prefer T = 6: 1 024 x 128^2 1 222 vs
     // 1 125 G cells*iter/s, 64 x 1024^2 1 258 vs 1 156, 16 x 1024^2 1 106 vs 1 064)
-    return c->n < ((size_t)1 << 22) ? 4 : 8;
+    const size_t cells = c->tb_ref_cells ? c->tb_ref_cells : c->n;
+    return cells < ((size_t)1 << 22) ? 4 : 8;
 }
+
+// the instantiated sweeps-per-pass: 1, 2, 4, 6, 8 (one helper for the planner and deff_last_launches)
+int clamp_tb_T(int T) { return T >= 8 ? 8 : T >= 6 ? 6 : T >= 4 ? 4 : T >= 2 ? 2 : 1; }
 
 // Harvest the row dictionary of the explicit system (kernels_dict.hpp).  On success the context
 // also has a matrix-free form (codes + tables); when the system has too many distinct rows it
@@ -144,7 +148,7 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
 {
     if (!c->have_field) return fail(DEFF_ESTATE, "no field: call deff_init_linear() or deff_set_field()");
     // an explicit system (host-assembled, 3-phase, ImpSolid) with few distinct rows also runs matrix-free
-    if (!c->have_matfree && c->have_explicit && !c->dict_tried && c->dict_enabled &&
+    if (!c->have_matfree && c->have_explicit && !c->dict_tried && c->dict_enabled && !c->wrap_links &&
         (c->kernel == DEFF_KERNEL_AUTO || c->kernel == DEFF_KERNEL_MATFREE || c->kernel == DEFF_KERNEL_MATFREE_TB))
         TRY(try_dict(c));
     TRY(resolve_kernel(c, &pl->kernel));
@@ -156,7 +160,7 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             // sweeps per pass (measured, G cells*iter/s: 4096^2 T=4 926, T=6 1063, T=8 1106; stacks of
             // 16 x 1024^2 peak at T=6; 1024^2 alone at T=4)
             int T = pl->T_override ? pl->T_override : (c->tb_T ? c->tb_T : default_tb_T(c));
-            T = T >= 8 ? 8 : T >= 6 ? 6 : T >= 4 ? 4 : T >= 2 ? 2 : 1;
+            T = clamp_tb_T(T);
             pl->T = T;
             // strips of 128 columns overlapping by 2*HW; a mesh wall needs no halo (kernels_tb.hpp)
             const int hw = (T + 1) & ~1, wout = TB_COLS - 2 * hw;
@@ -203,8 +207,10 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             const unsigned total = (unsigned)pl->tgx;
             pl->tblocks = (int)(((total + 7u) / 8u) * 8u);
             if (pl->tblocks > resident) pl->tblocks = resident >= 8 ? resident / 8 * 8 : 8;
-            c->plan_T = pl->T; c->plan_LY = pl->LY; c->plan_ntx = pl->ntx; c->plan_cpi = pl->tcpi;
-            c->plan_blocks = pl->tblocks;
+            if (!pl->T_override) {                       // the remainder plan of a slab (T = 1) is not "the" plan
+                c->plan_T = pl->T; c->plan_LY = pl->LY; c->plan_ntx = pl->ntx; c->plan_cpi = pl->tcpi;
+                c->plan_blocks = pl->tblocks;
+            }
             // the reference's non-zero link test matters only when a phase cannot diffuse
             pl->guard = c->lut_guard;
         }
@@ -656,6 +662,7 @@ try {
     SweepPlan pl;
     TRY(plan_sweeps(c, omega, &pl));
     if (pl.kernel != DEFF_KERNEL_MATFREE_TB) return fail(DEFF_ESTATE, "not on the temporally blocked kernel");
+    TRY(consolidate(c));
     const int n = pl.ntx * pl.tgy;
     *ntiles = n;
     if (!out) return DEFF_OK;
@@ -688,8 +695,7 @@ try {
         int k = 0;
         *sweeps_per_pass = 1;
         if (resolve_kernel(c, &k) == DEFF_OK && k == DEFF_KERNEL_MATFREE_TB) {
-            int T = c->tb_T ? c->tb_T : default_tb_T(c);
-            *sweeps_per_pass = T >= 8 ? 8 : T >= 6 ? 6 : T >= 4 ? 4 : 2;
+            *sweeps_per_pass = clamp_tb_T(c->tb_T ? c->tb_T : default_tb_T(c));
         }
     }
     return DEFF_OK;

@@ -66,6 +66,10 @@ struct deff_ctx {
     // li - dom_lo of a mesh_ny-row mesh.  Plain contexts: dom_lo = 0, mesh_ny = own_h = ny, halo = 0.
     bool slab = false;
     int dom_lo = 0, mesh_ny = 0, own_lo = 0, own_h = 0, halo = 0;
+    // cells the default sweeps-per-pass is keyed on: 0 = this context's own n; for a slab a figure derived from
+    // (nx, NY, number of slabs) alone, so that every slab / rank of one image plans the SAME T whatever its own
+    // row count (slabs differ by one row; a different T per slab would desynchronise passes and exchanges)
+    size_t tb_ref_cells = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -90,6 +94,11 @@ struct deff_ctx {
     bool have_matfree = false;
     bool dict_tried = false;        // a dictionary was already looked for in the current explicit system
     int dict_enabled = 1;
+    // an imported system (deff_set_system) with a non-zero W link in the first column or E link in the last:
+    // the reference's kernel addresses neighbours linearly (x[p-1], x[p+1], cuh:80-83), so such a link reads the
+    // neighbouring ROW's end cell.  Only the explicit / scalar kernels keep that addressing; the dictionary and the
+    // temporally blocked kernel treat a wall column's outer neighbour as absent -- such a system stays explicit.
+    bool wrap_links = false;
     double lut_omega = NAN;
     double Ds = 0, Df = 0;          // phase diffusivities of the native 2-phase system
 
@@ -244,6 +253,7 @@ int consolidate(deff_ctx *c);
 int explicit_from_image(deff_ctx *c);
 // api_solve.hip
 int default_tb_T(const deff_ctx *c);
+int clamp_tb_T(int T);
 int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl);
 void enqueue_sweep(deff_ctx *c, const SweepPlan &pl);
 void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl);

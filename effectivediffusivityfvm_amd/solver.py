@@ -190,15 +190,19 @@ class Solver:
             return 1
 
         def _done(_user, image_id, slot, res_ptr):
-            r = res_ptr[0]
-            out = SolveResult()
-            out.iters, out.checks, out.deff_raw, out.conv, out.loop_ms = r.iters, r.checks, r.deff_raw, r.conv, r.loop_ms
-            out.MFL = out.MFR = None
-            if want_fields:
-                x = np.empty((self.ny, self.nx), dtype=np.float64)
-                check(self._L.deff_get_slot_field(self._ctx, slot, x))
-                out.field = x
-            results[int(image_id)] = out
+            # an exception raised inside a ctypes callback is swallowed: record it, re-raise after the call
+            try:
+                r = res_ptr[0]
+                out = SolveResult()
+                out.iters, out.checks, out.deff_raw, out.conv, out.loop_ms = r.iters, r.checks, r.deff_raw, r.conv, r.loop_ms
+                out.MFL = out.MFR = None
+                if want_fields:
+                    x = np.empty((self.ny, self.nx), dtype=np.float64)
+                    check(self._L.deff_get_slot_field(self._ctx, slot, x))
+                    out.field = x
+                results[int(image_id)] = out
+            except Exception as e:          # noqa: BLE001
+                errors.append(e)
 
         nxt, dn = _capi.NEXT_IMAGE_FN(_next), _capi.IMAGE_DONE_FN(_done)
         rc = self._L.deff_solve_stream(self._ctx, W, H, ampX, ampY, Ds, Df, CL, CR, omega, tol, int(max_iter),
@@ -275,6 +279,18 @@ class SlabGroup:
 
     def set_tuning(self, key, value):
         check(self._L.deff_slab_group_set_tuning(self._g, key.encode(), int(value)))
+
+    def plans(self):
+        """Every slab's last temporally blocked launch plan (Solver.plan() per slab)."""
+        out = []
+        for r in range(self.nslabs):
+            d = {}
+            for key in ("tb_T", "tb_LY", "tb_strips", "tb_chunks_per_image", "tb_blocks"):
+                v = C.c_int()
+                check(self._L.deff_slab_group_get_plan(self._g, r, key.encode(), C.byref(v)))
+                d[key] = v.value
+            out.append(d)
+        return out
 
     def set_image(self, pix):
         pix = np.ascontiguousarray(pix, dtype=np.uint8)

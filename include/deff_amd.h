@@ -173,6 +173,8 @@ int deff_slab_group_create(int nslabs, const int *devices, int nx, int NY, deff_
 int deff_slab_group_destroy(deff_slab_group *g);
 int deff_slab_group_layout(const deff_slab_group *g, int *first_row, int *row_count);
 int deff_slab_group_set_tuning(deff_slab_group *g, const char *key, int value);
+/* deff_get_plan() of slab `slab`: every slab of an image plans the same sweeps-per-pass ("tb_T") */
+int deff_slab_group_get_plan(deff_slab_group *g, int slab, const char *key, int *value);
 int deff_slab_group_set_image(deff_slab_group *g, const uint8_t *pix /* NY*nx */);
 int deff_slab_group_synth_image(deff_slab_group *g, uint64_t seed, uint64_t img);
 int deff_slab_group_assemble_2phase(deff_slab_group *g, double Ds, double Df, double CL, double CR);

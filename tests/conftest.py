@@ -23,7 +23,14 @@ def recorded():
 
 @pytest.fixture(scope="session")
 def img00000():
-    return np.load(os.path.join(GOLDEN, "img00000_pix.npy"))
+    """00000.jpg as decoded by the reference's own stb_image (tests/golden/make_stb_fixture.py)."""
+    return np.load(os.path.join(GOLDEN, "img00000_pix_stb.npy"))
+
+
+@pytest.fixture(scope="session")
+def stb_recorded():
+    with open(os.path.join(GOLDEN, "stb_decode_recorded.json")) as f:
+        return json.load(f)
 
 
 @pytest.fixture(scope="session")

@@ -196,3 +196,31 @@ def solve_3phase(pix, DCS, DCF, DCG, CL, CR, tol, max_iter, flavour=None):
     it, deff, conv, x, _, _ = jacobi(A, b, x, D, CL, CR, tol, max_iter, flavour=flavour)
     stages.append(it)
     return dict(stage_sweeps=stages, deff=deff / DCF, conv=conv, SVF=svf, LVF=lvf, field=x, grid=grid, path=path)
+
+
+def solve_single_2phase_ramp(pix, DCS, DCF_max, CL, CR, tol, max_iter, ampX=1, ampY=1, flavour=None):
+    """SingleSim's DCF continuation, cuh:1713-1817, on the oracle: the fluid diffusivity is ramped
+    DCF = 100^count (100, 1e4, 1e6, ...) clipped to Df; every stage refills D, re-assembles and runs
+    JacobiGPU warm-started from the previous stage's field (x_vec is in/out, cuh:1793); after each
+    stage `deff /= DCF` (cuh:1802).  The loop condition is tested on the PREVIOUS DCF, starting from
+    10 (cuh:1714, :1761): for Df < 10 it never runs (the reference then prints uninitialised
+    memory -- returned here as stages == []).
+    Returns dict(stages=[(DCF, sweeps, deff_normalised, conv), ...], field)."""
+    H, W = pix.shape
+    nx, ny = W * ampX, H * ampY
+    x = linear_guess(nx, ny, CL, CR, flavour=flavour)           # cuh:1730-1734
+    DCF = 10.0
+    count = 1
+    stages = []
+    while DCF <= DCF_max:                                        # cuh:1761
+        DCF = float(100 ** count)                                # std::pow(100, count)
+        if DCF >= DCF_max:
+            DCF = DCF_max
+        D = fill_D_2phase(pix, DCF, DCS, ampX, ampY)             # cuh:1773-1785
+        A, b = discretize(D, CL, CR)                             # cuh:1789
+        it, deff, conv, x, _, _ = jacobi(A, b, x, D, CL, CR, tol, max_iter, flavour=flavour)   # cuh:1793
+        stages.append((DCF, it, deff / DCF, conv))               # cuh:1802
+        if DCF == DCF_max:
+            break
+        count += 1
+    return dict(stages=stages, field=x)

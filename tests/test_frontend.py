@@ -23,39 +23,68 @@ def built():
     return EXE
 
 
-def test_jpeg_decoder_matches_stb_image_statistics(built):
-    """SURVEY.md section 5 measured stb_image (the reference's decoder) against libjpeg on this
-    file: they differ by +-1 on exactly 41 pixels, none across a phase threshold.  The decoder
-    here must show exactly that signature against PIL's libjpeg, and the recorded porosity."""
+def test_jpeg_decoder_byte_equal_to_stb_image(built, img00000, stb_recorded):
+    """The reference decodes with stbi_load(name,&w,&h,&n,1) (Deff2D.cuh:342; stb_image.h:1306).
+    tests/golden/img00000_pix_stb.npy holds the bytes the reference's own stb_image.h v2.26 yields for
+    00000.jpg (compiled from /root/reference as it lies by tests/golden/make_stb_fixture.py): the decoder
+    here must give exactly those bytes."""
+    import hashlib
     import effectivediffusivityfvm_amd as pkg
-    from PIL import Image
     mine = pkg.load_jpeg_gray(os.path.join(GOLDEN, "00000.jpg"))
+    assert mine.shape == (128, 128) and mine.dtype == np.uint8
+    assert np.array_equal(mine, img00000)
+    rec = stb_recorded["00000.jpg"]
+    assert hashlib.sha256(mine.tobytes()).hexdigest() == rec["sha256"]
+    assert float((mine < 150).mean()) == rec["porosity_lt150"] == 0.3460693359375
+    # and it is NOT libjpeg's decode: the two differ by +-1 on 41 pixels (none across a threshold)
+    from PIL import Image
     ref = np.array(Image.open(os.path.join(GOLDEN, "00000.jpg")), dtype=np.uint8)
-    assert mine.shape == (128, 128)
     d = mine.astype(int) - ref.astype(int)
     assert np.abs(d).max() == 1 and int((d != 0).sum()) == 41
     for thr in (50, 150, 200):
         assert np.array_equal(mine < thr, ref < thr)
-    assert float((mine < 150).mean()) == 0.3460693359375
-    # the committed pixel fixture (PIL-decoded) gives the same phases
-    assert np.array_equal(np.load(os.path.join(GOLDEN, "img00000_pix.npy")) < 150, mine < 150)
 
 
-def test_jpeg_decoder_on_second_reference_image(built):
-    """00042.jpg (1002x2007, not committed: 771 KB): stb_image vs libjpeg differ on 9 809 pixels and
-    364-378 of them cross the 150 threshold.  Only runs where the reference is mounted."""
+def test_jpeg_decoder_on_second_reference_image(built, stb_recorded):
+    """00042.jpg (1002x2007, the image the shipped input.txt names; 771 KB, not committed): the decode must
+    hash to the SHA-256 of the reference's stb_image decode (stb_decode_recorded.json) -- on this image
+    libjpeg would flip 364 pixels across the 150 threshold.  Only runs where the reference is mounted."""
     path = "/root/reference/Deff2DGPU/00042.jpg"
     if not os.path.exists(path):
         pytest.skip("reference not mounted")
+    import hashlib
     import effectivediffusivityfvm_amd as pkg
     from PIL import Image
     mine = pkg.load_jpeg_gray(path)
+    rec = stb_recorded["00042.jpg"]
+    assert list(mine.shape) == rec["shape"] == [2007, 1002]
+    assert hashlib.sha256(mine.tobytes()).hexdigest() == rec["sha256"]
+    assert int((mine < 50).sum()) == rec["count_lt50"] and int((mine > 200).sum()) == rec["count_gt200"]
+    assert int((mine < 150).sum()) == rec["count_lt150"]
     ref = np.array(Image.open(path), dtype=np.uint8)
-    assert mine.shape == (2007, 1002)
     d = mine.astype(int) - ref.astype(int)
     assert np.abs(d).max() == 1 and int((d != 0).sum()) == 9809
     assert 364 <= int(((mine < 150) != (ref < 150)).sum()) <= 378
-    assert np.array_equal(mine < 50, ref < 50) and np.array_equal(mine > 200, ref > 200)
+
+
+def test_stb_fixture_regenerates_from_the_reference(img00000, stb_recorded, tmp_path):
+    """Where /root/reference is mounted: compile the reference's stb_image.h as it lies (plain C, gcc, a
+    12-line program of ours -- tests/golden/make_stb_fixture.py) and check that the committed pixel fixture and
+    hashes are what it yields today.  The GPU box has no reference: skipped there."""
+    if not os.path.exists("/root/reference/Deff2DGPU/stb_image.h"):
+        pytest.skip("reference not mounted")
+    import hashlib
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_stb_fixture", os.path.join(GOLDEN, "make_stb_fixture.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    exe = mk.build_decoder(str(tmp_path))
+    pix, n = mk.stb_decode(exe, "/root/reference/Deff2DGPU/00000.jpg", str(tmp_path))
+    assert n == 1 and np.array_equal(pix, img00000)
+    pix42, n42 = mk.stb_decode(exe, "/root/reference/Deff2DGPU/00042.jpg", str(tmp_path))
+    assert n42 == 1 and hashlib.sha256(pix42.tobytes()).hexdigest() == stb_recorded["00042.jpg"]["sha256"]
+    # the committed copy of 00000.jpg is the reference's file
+    assert open(os.path.join(GOLDEN, "00000.jpg"), "rb").read() == open("/root/reference/Deff2DGPU/00000.jpg", "rb").read()
 
 
 def test_jpeg_decoder_rejects_what_the_reference_rejects(built, tmp_path):
@@ -152,6 +181,58 @@ def test_driver_2phase_batch_config1(built, tmp_path, recorded):
     field = np.fromfile(tmp_path / "field_00000_128x128.f64").reshape(128, 128)
     gold = np.load(os.path.join(GOLDEN, "img00000_field.npy"))
     assert np.linalg.norm(field - gold) / np.linalg.norm(gold) <= 1e-6 and np.array_equal(field, gold)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Df,want_dcf", [("1e4", [100.0, 1e4]), ("250", [100.0, 250.0]), ("100", [100.0]),
+                                         ("1e6", [100.0, 1e4, 1e6])])
+def test_driver_single_sim_dcf_ramp(built, tmp_path, oracle, img00000, Df, want_dcf):
+    """RunBatch 0, 2 phases: SingleSim's DCF continuation (Deff2D.cuh:1759-1817) -- the fluid diffusivity ramped
+    100, 1e4, ... up to Df, every stage re-assembled and warm-started from the previous field, deff /= DCF per
+    stage.  Per-stage iteration counts, the final Deff / conv and the final field must equal the oracle's
+    restatement of the ramp (tests/oracle_binding.solve_single_2phase_ramp) on the stb-decoded 00000.jpg."""
+    shutil.copy(os.path.join(GOLDEN, "00000.jpg"), tmp_path / "00000.jpg")
+    _write_input(tmp_path / "input.txt", Phases=2, Ds="1e-3", Df=Df, MeshAmpX=1, MeshAmpY=1, InputName="00000.jpg",
+                 CR=1, CL=0, OutputName="out.csv", printCMap=0, Convergence="1e-6", MaxIter="3e5", Verbose=1,
+                 RunBatch=0, NumImages=1)
+    r = subprocess.run([EXE, "input.txt", "--json", "res.json", "--field-bin", "f"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    res = json.load(open(tmp_path / "res.json"))["results"][0]
+    want = oracle.solve_single_2phase_ramp(img00000, 1e-3, float(Df), 0.0, 1.0, 1e-6, 300000)
+    assert [st[0] for st in want["stages"]] == want_dcf
+    assert res["stage_iterations"] == [st[1] for st in want["stages"]]
+    assert res["iterations"] == want["stages"][-1][1]
+    assert res["Deff"] == want["stages"][-1][2] and res["converge"] == want["stages"][-1][3]
+    # the per-stage lines the reference prints under Verbose: 1 (cuh:1796-1808), one per stage
+    for dcf, it, deff, _ in want["stages"]:
+        assert f"Iterations taken = {it}\n" in r.stdout
+        assert f"DCF = {dcf:g}, Deff {deff:g}\n" in r.stdout
+    field = np.fromfile(tmp_path / "f_00000_128x128.f64").reshape(128, 128)
+    assert np.linalg.norm(field - want["field"]) / np.linalg.norm(want["field"]) <= 1e-6
+    assert np.array_equal(field, want["field"])
+    cols = open(tmp_path / "out.csv").read().splitlines()[1].split(",")
+    assert cols[0] == "00000.jpg" or cols[0] == "0"
+    assert cols[3] == f"{want['stages'][-1][2]:f}"                  # outputSingle prints Deff with %f, cuh:184
+
+
+@pytest.mark.gpu
+def test_driver_single_sim_below_ten_is_flagged(built, tmp_path, oracle, img00000):
+    """Df < 10: the reference's ramp loop `while (DCF <= DCF_Max)` starts from DCF = 10 (cuh:1714, :1761), runs no
+    solve and writes uninitialised memory to the CSV.  The oracle restatement shows the no-op; deff2d says so on
+    stderr and solves once with Df, i.e. gives the BatchSim value."""
+    assert oracle.solve_single_2phase_ramp(img00000, 1e-3, 5.0, 0.0, 1.0, 1e-6, 1000)["stages"] == []
+    shutil.copy(os.path.join(GOLDEN, "00000.jpg"), tmp_path / "00000.jpg")
+    _write_input(tmp_path / "input.txt", Phases=2, Ds="1e-3", Df=5, MeshAmpX=1, MeshAmpY=1, InputName="00000.jpg",
+                 CR=1, CL=0, OutputName="out.csv", printCMap=0, Convergence="1e-6", MaxIter="3e5", Verbose=0,
+                 RunBatch=0, NumImages=1)
+    r = subprocess.run([EXE, "input.txt", "--json", "res.json"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "runs no solve" in r.stderr
+    res = json.load(open(tmp_path / "res.json"))["results"][0]
+    D = oracle.fill_D_2phase(img00000, 5.0, 1e-3)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    it, deff, conv, _, _, _ = oracle.jacobi(A, b, oracle.linear_guess(128, 128, 0.0, 1.0), D, 0.0, 1.0, 1e-6, 300000)
+    assert (res["iterations"], res["Deff"], res["converge"]) == (it, deff / 5.0, conv)
 
 
 @pytest.mark.gpu

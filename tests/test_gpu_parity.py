@@ -1305,3 +1305,65 @@ def test_errors_are_loud(pkg):
             s.sweeps(1)                      # no system
         with pytest.raises(pkg.DeffError):
             s.set_image(np.zeros((8, 8), dtype=np.uint8))   # shape mismatch
+
+
+def test_wall_column_links_keep_linear_addressing(pkg, oracle):
+    """A caller-built A may link a wall column to the neighbouring ROW (A[p][1] != 0 in column 0 reads x[p-1], the
+    previous row's last cell: the reference's kernel addresses linearly, cuh:80-83).  The reference's own assembly
+    never produces such links (cuh:849-864); when a caller does, the system must stay on the explicit kernels, which
+    keep that addressing, and match the oracle -- not be moved to the dictionary kernels, whose walls have no
+    outer neighbour.  An odd width (padded rows) cannot represent it and is refused."""
+    rng = np.random.default_rng(5)
+    nx, ny = 64, 24
+    pix = rand_mask(rng, nx, ny)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-2)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    A = A.copy().reshape(ny, nx, 5)
+    A[1:, 0, 1] = -0.125            # W link of column 0 -> previous row's last cell (row 0 would read x[-1]: left alone)
+    A[:-1, -1, 2] = -0.25           # E link of the last column -> next row's first cell
+    A = A.reshape(-1, 5)
+    x0 = rng.random((ny, nx))
+    want = oracle.sweeps(A, b, x0, 11)
+    for kernel in ("auto", "matfree_tb", "explicit", "scalar"):
+        with pkg.Solver(nx, ny, kernel=kernel) as s:
+            s.set_system(A, b, D, 0.0, 1.0)
+            s.set_field(x0)
+            s.sweeps(11)
+            assert s.kernel_in_use() in ("explicit", "scalar")
+            assert_field(s.get_field(), want)
+    # the same rows without the wrap links ARE dictionary-coded (the control)
+    A2, b2 = oracle.discretize(D, 0.0, 1.0)
+    with pkg.Solver(nx, ny) as s:
+        s.set_system(A2, b2, D, 0.0, 1.0)
+        s.set_field(x0)
+        s.sweeps(11)
+        assert s.kernel_in_use() == "matfree_tb"
+        assert_field(s.get_field(), oracle.sweeps(A2, b2, x0, 11))
+    # odd width: refused, with a message
+    nxo = 63
+    Do = oracle.fill_D_2phase(rand_mask(rng, nxo, ny), 1.0, 1e-2)
+    Ao, bo = oracle.discretize(Do, 0.0, 1.0)
+    Ao = Ao.copy().reshape(ny, nxo, 5)
+    Ao[3, 0, 1] = -0.5
+    with pkg.Solver(nxo, ny) as s:
+        with pytest.raises(pkg.DeffError, match="wall column"):
+            s.set_system(Ao.reshape(-1, 5), bo, Do, 0.0, 1.0)
+
+
+def test_stream_callback_errors_surface(pkg, monkeypatch):
+    """An exception inside the image-done callback of solve_stream must be re-raised after the call (ctypes would
+    otherwise swallow it and the caller would see a KeyError much later)."""
+    import effectivediffusivityfvm_amd.solver as solver_mod
+
+    class Boom(RuntimeError):
+        pass
+
+    def broken():
+        raise Boom("result object could not be built")
+
+    rng = np.random.default_rng(2)
+    imgs = [rand_mask(rng, 32, 16) for _ in range(3)]
+    with pkg.Solver(32, 16, nimg=2) as s:
+        monkeypatch.setattr(solver_mod, "SolveResult", broken)
+        with pytest.raises(Boom):
+            s.solve_stream(iter(imgs), 1e-2, 1.0, 0.0, 1.0, 1e-3, 200, check_every=50)
