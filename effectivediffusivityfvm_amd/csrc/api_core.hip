@@ -208,6 +208,9 @@ try {
     else if (!strcmp(key, "serpentine")) c->serpentine = value ? 1 : 0;
     else if (!strcmp(key, "tb_T")) c->tb_T = value;
     else if (!strcmp(key, "tb_LY")) c->tb_LY = value;
+    else if (!strcmp(key, "tb_impl")) c->tb_impl = value > 2 ? 0 : value;
+    else if (!strcmp(key, "tb_R")) c->tb_R = value;
+    else if (!strcmp(key, "tb_NW")) c->tb_NW = value;
     else if (!strcmp(key, "dict")) c->dict_enabled = value ? 1 : 0;
     else if (!strcmp(key, "tb_xmajor")) c->tb_xmajor = value ? 1 : 0;
     else if (!strcmp(key, "fma")) c->fma = value ? 1 : 0;
@@ -227,6 +230,9 @@ try {
     else if (!strcmp(key, "tb_strips")) *value = c->plan_ntx;
     else if (!strcmp(key, "tb_chunks_per_image")) *value = c->plan_cpi;
     else if (!strcmp(key, "tb_blocks")) *value = c->plan_blocks;
+    else if (!strcmp(key, "tb_impl")) *value = c->plan_impl;
+    else if (!strcmp(key, "tb_R")) *value = c->plan_R;
+    else if (!strcmp(key, "tb_NW")) *value = c->plan_NW;
     else return fail(DEFF_EINVAL, "unknown plan key '%s'", key);
     return DEFF_OK;
 }

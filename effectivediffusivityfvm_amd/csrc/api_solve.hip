@@ -5,6 +5,7 @@
 #include "kernels_dict.hpp"
 #include "kernels_sweep.hpp"
 #include "kernels_tb.hpp"
+#include "kernels_wgtile.hpp"
 
 // ----------------------------------------------------------- sweeps -------
 
@@ -47,6 +48,41 @@ static int tb_resident_blocks(const deff_ctx *c, int T, bool fma, bool guard, in
     return DEFF_OK;
 }
 
+// ---- workgroup-tile form (kernels_wgtile.hpp): instantiated for T in {4, 8} x R in {4, 6, 7} rows per wave
+// (R = 8 needs 256 VGPRs + 148 B of scratch per lane and ran 40 % SLOWER than R = 6: the spills sit in the sweep loop)
+#define WGT_DISPATCH_FG(T_, R_, F_, G_, CALL)                                                   \
+    switch (((F_) ? 2 : 0) + ((G_) ? 1 : 0)) {                                                 \
+    case 1: { CALL(T_, R_, false, true); } break;  case 2: { CALL(T_, R_, true, false); } break; \
+    case 3: { CALL(T_, R_, true, true); } break;   default: { CALL(T_, R_, false, false); } break; \
+    }
+#define WGT_DISPATCH_R(T_, R_, F_, G_, CALL)                                                    \
+    if ((R_) == 4) { WGT_DISPATCH_FG(T_, 4, F_, G_, CALL) }                                     \
+    else if ((R_) == 6) { WGT_DISPATCH_FG(T_, 6, F_, G_, CALL) }                                \
+    else { WGT_DISPATCH_FG(T_, 7, F_, G_, CALL) }
+#define WGT_DISPATCH(T_, R_, F_, G_, CALL)                                                      \
+    do {                                                                                       \
+        if ((T_) == 4) { WGT_DISPATCH_R(4, R_, F_, G_, CALL) } else { WGT_DISPATCH_R(8, R_, F_, G_, CALL) } \
+    } while (0)
+
+template <int T, int R, bool F, bool G>
+static int wgt_occ(int *per_cu)
+{
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_sweep_wgtile<T, R, F, G>, WGT_WAVES * 64, 0));
+    return DEFF_OK;
+}
+
+static int wgt_resident_blocks(const deff_ctx *c, int T, int R, bool fma, bool guard, int *resident)
+{
+    int per_cu = 0, cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+#define OCC_CALL(T_, R_, C_, G_) TRY((wgt_occ<T_, R_, C_, G_>(&per_cu)))
+    WGT_DISPATCH(T, R, fma, guard, OCC_CALL);
+#undef OCC_CALL
+    if (per_cu < 1) per_cu = 1;
+    *resident = per_cu * cus;
+    return DEFF_OK;
+}
+
 static int pick_R(int requested, int dflt)
 {
     const int r = requested ? requested : dflt;
@@ -63,9 +99,22 @@ static void tile_grid(const deff_ctx *c, int cols_per_block, int rows, SweepPlan
     pl->blocks = (int)(((total + 7u) / 8u) * 8u);      // see xcd_tile()
 }
 
+// Which form of the temporally blocked pass a context gets when the caller does not say (tb_impl = 0): workgroup tiles
+// (kernels_wgtile.hpp) for ONE image below 4 Mi cells, where the streaming kernel has too few tiles to fill the chip and
+// a tile's dependency chain sets the time of a pass (measured, G cells*iter/s, streaming / workgroup tiles: 512^2 106 / 231,
+// 1024^2 316 / 556, 1536^2 455 / 613, 2048^2 682 / 678, 4096^2 1 128 / 742); stacks and everything larger stream.
+// Keyed on tb_ref_cells for slabs, so that every slab of an image takes the same decision (and the same T).
+int default_tb_impl(const deff_ctx *c)
+{
+    const size_t cells = c->tb_ref_cells ? c->tb_ref_cells : c->n;
+    return (c->nimg == 1 && cells < ((size_t)1 << 22)) ? 2 : 1;
+}
+
 int default_tb_T(const deff_ctx *c)
 {
-    // below 4 Mi cells the launch is latency-bound and T = 4 wins; above, T = 8 everywhere (with the
+    // workgroup tiles: 8 sweeps per pass amortise the launch gap and the first-load latency (1024^2: T = 8 556, T = 4 457)
+    if ((c->tb_impl ? c->tb_impl : default_tb_impl(c)) == 2) return 8;
+    // streaming: below 4 Mi cells the launch is latency-bound and T = 4 wins; above, T = 8 everywhere (with the
     // prefetch really in flight, kernels_tb.hpp, stacks no longer prefer T = 6: 1 024 x 128^2 1 222 vs
     // 1 125 G cells*iter/s, 64 x 1024^2 1 258 vs 1 156, 16 x 1024^2 1 106 vs 1 064)
     const size_t cells = c->tb_ref_cells ? c->tb_ref_cells : c->n;
@@ -173,6 +222,45 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             const bool use_b = c->tb_wall_halo == 0 ? true : (c->tb_wall_halo == 1 ? false : ntx_b < ntx_a);
             pl->shift = use_b ? 0 : hw;
             pl->ntx = use_b ? ntx_b : ntx_a;
+            // Form of the pass.  Workgroup tiles exist for T = 4 and 8; slabs' T = 1 remainder passes and the other
+            // T stay on the streaming kernel.
+            const int want_impl = c->tb_impl ? c->tb_impl : default_tb_impl(c);
+            if (want_impl == 2 && (T == 4 || T == 8) && !pl->T_override) {
+                pl->impl = 2;
+                int resident = c->tb_wg;
+                if (c->tb_R == 4 || c->tb_R == 6 || c->tb_R == 7) {
+                    pl->R = c->tb_R;
+                } else {
+                    // rows per wave: the fewest (shortest sweeps) whose tiles are all resident at once; if none is, 6
+                    // (7 needs 256 VGPRs and a few spilled registers: fine for one round, slower over several)
+                    pl->R = 6;
+                    for (int R : {4, 6, 7}) {
+                        const int lymax = wgt_rows_owned(T, R);
+                        if (lymax < 1) continue;
+                        int res = resident;
+                        if (!res) TRY(wgt_resident_blocks(c, T, R, pl->fma, c->lut_guard, &res));
+                        const long tiles = (long)pl->ntx * ((c->own_h + lymax - 1) / lymax) * c->nimg;
+                        if (tiles <= res) { pl->R = R; break; }
+                    }
+                }
+                pl->NW = WGT_WAVES;
+                const int lymax = wgt_rows_owned(T, pl->R);
+                // rows a tile owns: at most 8R - 2T; spread the image's rows evenly over its row tiles
+                int cpi = (c->own_h + lymax - 1) / lymax;
+                if (c->tb_LY > 0 && c->tb_LY < lymax) cpi = (c->own_h + c->tb_LY - 1) / c->tb_LY;
+                pl->LY = (c->own_h + cpi - 1) / cpi;
+                pl->tcpi = (c->own_h + pl->LY - 1) / pl->LY;
+                pl->tgy = pl->tcpi * c->nimg;
+                const long tiles = (long)pl->ntx * pl->tgy;
+                if (!resident) TRY(wgt_resident_blocks(c, T, pl->R, pl->fma, c->lut_guard, &resident));
+                pl->tgx = (int)tiles;
+                pl->tblocks = (int)(((tiles + 7) / 8) * 8);
+                if (pl->tblocks > resident) pl->tblocks = resident >= 8 ? resident / 8 * 8 : 8;
+                pl->guard = c->lut_guard;
+                c->plan_T = pl->T; c->plan_LY = pl->LY; c->plan_ntx = pl->ntx; c->plan_cpi = pl->tcpi;
+                c->plan_blocks = pl->tblocks; c->plan_impl = 2; c->plan_R = pl->R; c->plan_NW = pl->NW;
+            } else {
+            pl->impl = 1;
             // Rows per chunk.  Workgroups are persistent, so a pass takes `rounds` tiles per wave slot
             // (one round = as many wave tiles as are resident at once), and a tile costs its LY rows
             // + T steps that drain the pipeline + T rows of halo above it unless it starts at the top
@@ -209,10 +297,11 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             if (pl->tblocks > resident) pl->tblocks = resident >= 8 ? resident / 8 * 8 : 8;
             if (!pl->T_override) {                       // the remainder plan of a slab (T = 1) is not "the" plan
                 c->plan_T = pl->T; c->plan_LY = pl->LY; c->plan_ntx = pl->ntx; c->plan_cpi = pl->tcpi;
-                c->plan_blocks = pl->tblocks;
+                c->plan_blocks = pl->tblocks; c->plan_impl = 1; c->plan_R = 0;
             }
             // the reference's non-zero link test matters only when a phase cannot diffuse
             pl->guard = c->lut_guard;
+            }
         }
         tile_grid(c, 256 * 2, pick_R(c->rows_matfree, c->n >= ((size_t)1 << 21) ? 8 : 2), pl);
         // persistent grid: a few workgroups per CU walk the tiles (tables loaded once each)
@@ -297,6 +386,17 @@ void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl)
     double *xout = c->x[c->cur ^ 1];
     const int flip = c->serpentine ? c->cur : 0;
     const uint8_t *mask = c->masked ? c->active : nullptr;
+    if (pl.impl == 2) {
+#define LAUNCH_WGT(T_, R_, C_, G_)                                                                             \
+    hipLaunchKernelGGL((k_sweep_wgtile<T_, R_, C_, G_>), dim3(pl.tblocks), dim3(WGT_WAVES * 64), 0, c->stream, c->lut, \
+                       c->code, xin, xout, c->nx, c->mesh_ny, c->ny, c->dom_lo, c->own_lo, c->own_h, pl.tcpi, pl.LY, \
+                       mask, pl.ntx, pl.tgy, c->tb_xmajor, (c->lut_allb || c->nx != c->nxt) ? 1 : 0,         \
+                       c->lut_nrows, pl.shift, pl.omw, c->tb_stamps)
+        WGT_DISPATCH(pl.T, pl.R, pl.fma, pl.guard, LAUNCH_WGT);
+#undef LAUNCH_WGT
+        c->cur ^= 1;
+        return;
+    }
 #define LAUNCH_TB(T_, C_, G_)                                                                                  \
     hipLaunchKernelGGL((k_sweep_matfree_tb<T_, C_, G_>), dim3(pl.tblocks), dim3(256), 0, c->stream, c->lut,    \
                        c->code, xin, xout, c->nx, c->mesh_ny, c->ny, c->dom_lo, c->own_lo, c->own_h, pl.tcpi, \
@@ -663,7 +763,9 @@ try {
     TRY(plan_sweeps(c, omega, &pl));
     if (pl.kernel != DEFF_KERNEL_MATFREE_TB) return fail(DEFF_ESTATE, "not on the temporally blocked kernel");
     TRY(consolidate(c));
-    const int n = pl.ntx * pl.tgy;
+    // streaming form: 2 stamps per wave tile; workgroup-tile form: T + 4 per tile, flattened -- *ntiles is always
+    // the number of PAIRS the buffer must hold
+    const int n = pl.impl == 2 ? (pl.ntx * pl.tgy * (pl.T + 4) + 1) / 2 : pl.ntx * pl.tgy;
     *ntiles = n;
     if (!out) return DEFF_OK;
     HIP_TRY(hipMalloc((void **)&c->tb_stamps, sizeof(unsigned long long) * 2 * n));

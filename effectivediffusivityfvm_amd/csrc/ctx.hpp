@@ -136,6 +136,10 @@ struct deff_ctx {
     unsigned long long *tb_stamps = nullptr;     // diagnostics: per wave-tile start/end clocks (deff_debug_tb_stamps)
     int tb_wall_halo = 2;                        // strip placement: 1 = halo also outside the walls, 0 = not, 2 = whichever needs fewer strips
     int plan_T = 0, plan_LY = 0, plan_ntx = 0, plan_cpi = 0, plan_blocks = 0;   // last temporally blocked plan
+    int plan_impl = 0, plan_R = 0, plan_NW = 0;
+    // form of a temporally blocked pass: 0 = chosen by the planner, 1 = streaming (kernels_tb.hpp: one wave per tile),
+    // 2 = workgroup tiles (kernels_wgtile.hpp: 8 waves per tile, rows resident in registers); tb_R = rows per wave there
+    int tb_impl = 0, tb_R = 0, tb_NW = 0;
     int fma = 0;                                 // contracted arithmetic (kernels_sweep.hpp), opt-in
     int tb_xmajor = 1;                           // wave-tile numbering of the temporally blocked kernel
     int64_t last_launches = 0;                   // sweep-kernel launches of the last deff_sweeps()/deff_solve()
@@ -241,6 +245,7 @@ struct SweepPlan {
     int shift = 0;                                        // column shift of the strips (0: no halo outside the walls)
     int T_override = 0;                                   // slab mode plans a T = 1 pass for remainders
     bool guard = false;
+    int impl = 1, R = 0, NW = 8;                          // 1 = streaming kernel, 2 = workgroup tiles of NW waves x R rows
 };
 
 // api_core.hip
@@ -254,6 +259,7 @@ int explicit_from_image(deff_ctx *c);
 // api_solve.hip
 int default_tb_T(const deff_ctx *c);
 int clamp_tb_T(int T);
+int default_tb_impl(const deff_ctx *c);
 int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl);
 void enqueue_sweep(deff_ctx *c, const SweepPlan &pl);
 void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl);

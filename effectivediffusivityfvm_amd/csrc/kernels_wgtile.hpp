@@ -1,0 +1,316 @@
+// kernels_wgtile.hpp -- matrix-free sweeps with temporal blocking, workgroup-tile form:
+// T weighted-Jacobi sweeps per pass over HBM on a tile that stays IN REGISTERS for the whole pass
+// (gfx950, wave64, FP64).
+//
+// Same arithmetic as every other sweep kernel (updateX_SOR, Deff2DGPU/Deff2D.cuh:69-92, through
+// tb_cell()), same legality argument as kernels_tb.hpp (the reference inspects the field only every
+// 10 000 sweeps, cuh:1243), bit-identical results.
+//
+// Why a second form.  In the streaming kernel (kernels_tb.hpp) ONE wave carries a tile through all T
+// levels, a row at a time: every level of a step depends on the level before it, so a tile is a
+// chain of (rows + 2T) x T dependent level-steps.  That is fine when there are far more tiles than
+// wave slots (4096^2 and up), and slow when there are not: ONE 1024^2 image is ~2 300 tiles of 4 rows
+// whose 8 halo rows, first-load latency and ~600-clock level-steps bound a pass at ~10 us whatever
+// the chip could do (BASELINE config #2 ran at 24 % of the large-image rate).
+//
+// Here a WORKGROUP of 8 waves owns a tile of 8R rows x 128 columns (halo included).  Wave w holds rows
+// [wR, wR + R) in registers (2 cells per lane, like the streaming kernel: W/E neighbours by DPP).  A
+// sweep updates all rows in place; only the first and the last row of every wave are needed by another
+// wave, and they travel through an LDS mailbox (double-buffered: ONE s_barrier per sweep, reached after the
+// wave's interior rows are done, so that waiting for the slowest wave overlaps useful work).  The R
+// rows of a wave are independent within a sweep, so a wave has instruction-level parallelism where the
+// streaming kernel has a dependency chain, and it loads its rows in one burst and never reloads them.
+// And because a row stays with its wave for the whole pass, so do its MATRIX ROWS: the coefficients of the
+// wave's cells are looked up in the dictionary ONCE per pass and kept in registers (20 VGPRs per tile row),
+// so a sweep is pure arithmetic -- 22 FP64 + 4 DPP per tile row, no LDS lookup (tools/ubench: a sweep level
+// costs 109 clocks with the coefficients in registers against 151 with ten ds_read_b64 in front of it).
+// The price is the barrier: the waves of a tile advance in lock-step once per sweep.
+//
+// Halo: after t sweeps the outermost t rows / columns of a tile are stale, so a tile produces
+// up to 8R - 2T rows x (128 - 2*HW) columns; rows that no owned cell depends on any more are skipped sweep by
+// sweep (wave-uniform tests), columns cannot be (they are lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels_tb.hpp"
+
+namespace deff {
+
+constexpr int WGT_WAVES = 8;                                   // waves per workgroup tile (512 threads, 2 per SIMD)
+
+// most rows a tile of 8 waves x R rows per wave can OWN after a pass of T sweeps
+constexpr int wgt_rows_owned(int T, int R) { return WGT_WAVES * R - 2 * T; }
+
+// The matrix rows of a lane's two cells (c0 = w/A0 and the four links; b separately: it is zero away from the walls).
+struct WgtCoef {
+    double c0[2], aW[2], aE[2], aS[2], aN[2];
+};
+
+template <bool WALL>
+__device__ __forceinline__ void wgt_lookup(const double *lut, unsigned codes, WgtCoef &k, double2 &b)
+{
+    constexpr int PS = LUT_PLANE_STRIDE * 8;
+    double bb[2] = {0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const unsigned off = h ? (codes >> 16) : (codes & 0xFFFFu);
+        const char *base = reinterpret_cast<const char *>(lut) + off;
+        k.c0[h] = *reinterpret_cast<const double *>(base);
+        k.aW[h] = *reinterpret_cast<const double *>(base + PS);
+        k.aE[h] = *reinterpret_cast<const double *>(base + 2 * PS);
+        k.aS[h] = *reinterpret_cast<const double *>(base + 3 * PS);
+        k.aN[h] = *reinterpret_cast<const double *>(base + 4 * PS);
+        if constexpr (WALL) bb[h] = *reinterpret_cast<const double *>(base + 5 * PS);
+    }
+    b = make_double2(bb[0], bb[1]);
+}
+
+// NROWS tile rows (2 cells per lane each) updated TOGETHER, one arithmetic stage at a time over all of them: the
+// 2*NROWS cells are independent, so every FP64 instruction has 2*NROWS - 1 others between itself and the one that
+// consumes its result.  (Written cell by cell, hipcc emits each cell's seven-deep chain back to back -- measured 13
+// clocks per FP64 instruction on a SIMD holding two such waves.)  The arithmetic per cell is tb_cell()'s
+// (kernels_tb.hpp), i.e. updateX_SOR's (cuh:69-92), operation for operation.
+template <int NROWS, bool GUARD, bool FMA>
+__device__ __forceinline__ void wgt_rows(const WgtCoef *const (&k)[NROWS], const double2 (&b)[NROWS],
+                                         const double2 (&n_)[NROWS], const double2 (&c_)[NROWS],
+                                         const double2 (&s_)[NROWS], double omw, double2 (&out)[NROWS])
+{
+    constexpr int G = 2 * NROWS;
+    double xw[G], xe[G], xc[G], xs[G], xn[G], sg[G];
+#pragma unroll
+    for (int q = 0; q < NROWS; ++q) {
+        xw[2 * q] = from_lane_below(c_[q].y);  xe[2 * q] = c_[q].y;
+        xw[2 * q + 1] = c_[q].x;               xe[2 * q + 1] = from_lane_above(c_[q].x);
+        xc[2 * q] = c_[q].x; xc[2 * q + 1] = c_[q].y;
+        xs[2 * q] = s_[q].x; xs[2 * q + 1] = s_[q].y;
+        xn[2 * q] = n_[q].x; xn[2 * q + 1] = n_[q].y;
+    }
+    if constexpr (GUARD) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const WgtCoef &kk = *k[g >> 1];
+            const int h = g & 1;
+            sg[g] = jacobi_cell<FMA>(kk.c0[h], kk.aW[h], kk.aE[h], kk.aS[h], kk.aN[h], h ? b[g >> 1].y : b[g >> 1].x,
+                                     xc[g], xw[g], xe[g], xs[g], xn[g], omw);
+        }
+    } else {
+        double om[G];
+        // the leading `0 +` of the reference's sigma is bit-neutral here, see tb_cell()
+#pragma unroll
+        for (int g = 0; g < G; ++g) sg[g] = k[g >> 1]->aW[g & 1] * xw[g];
+#pragma unroll
+        for (int g = 0; g < G; ++g) sg[g] = mul_add<FMA>(k[g >> 1]->aE[g & 1], xe[g], sg[g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) sg[g] = mul_add<FMA>(k[g >> 1]->aS[g & 1], xs[g], sg[g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) sg[g] = mul_add<FMA>(k[g >> 1]->aN[g & 1], xn[g], sg[g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) sg[g] = ((g & 1) ? b[g >> 1].y : b[g >> 1].x) - sg[g];
+        if constexpr (!FMA) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) om[g] = omw * xc[g];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) sg[g] = k[g >> 1]->c0[g & 1] * sg[g];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if constexpr (FMA) sg[g] = __builtin_fma(omw, xc[g], sg[g]);
+            else sg[g] = om[g] + sg[g];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NROWS; ++q) out[q] = make_double2(sg[2 * q], sg[2 * q + 1]);
+}
+
+// grid: persistent workgroups of 8 waves; tiles (strip tx, row tile ty) numbered like the streaming
+// kernel's wave tiles (x-major: neighbouring strips adjacent; per XCD a contiguous run).
+// Geometry parameters as k_sweep_matfree_tb: image k of a stack has its mesh rows at
+// [dom_lo + k*img_stride, ... + ny) and its owned rows at [own_lo + k*img_stride, ... + own_h).
+// ly = rows a tile owns (<= 8R - 2T; the planner spreads an image's rows evenly over its cpi row tiles).
+template <int T, int R, bool FMA, bool GUARD>
+__global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgtile(const double *__restrict__ lut_g,
+                                                                    const uint16_t *__restrict__ code,
+                                                                    const double *__restrict__ x,
+                                                                    double *__restrict__ xnew, int nx, int ny,
+                                                                    int img_stride, int dom_lo, int own_lo,
+                                                                    int own_h, int cpi, int ly,
+                                                                    const uint8_t *__restrict__ active,
+                                                                    int ntx, int gy, int xmajor, int allb,
+                                                                    int nrows, int shift, double omw,
+                                                                    unsigned long long *__restrict__ stamps)
+{
+    constexpr int NW = WGT_WAVES;
+    static_assert(T >= 1 && T <= 8 && R >= 4, "unsupported tile");
+    static_assert(LUT_PLANES * LUT_MAX_ROWS <= 6 * WGT_WAVES * 64, "dictionary fetch assumes <= 6 doubles per thread");
+    static_assert(wgt_rows_owned(T, R) >= 1, "tile owns no row");
+    constexpr int HW = (T + 1) & ~1;               // column halo, even (16-B lane pairs), as tb_strip
+    constexpr int WOUT = TB_COLS - 2 * HW;
+
+    __shared__ double lut[LUT_DOUBLES];
+    __shared__ double2 edge[2][NW][2][64];         // [parity][wave][first / last row][lane]: 32 KiB
+    // diagnostics only (tools/wgt_stamps.py): 100 MHz wall clock at kernel entry, dictionary loaded, rows loaded, after every
+    // sweep, after the stores -- T + 4 values per tile, written by one lane, read by nobody on the device
+    const unsigned long long t_entry = stamps ? wall_clock64() : 0ull;
+    unsigned long long t_lut = 0ull;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned total = (unsigned)ntx * (unsigned)gy;
+    const unsigned per = (total + 7u) / 8u;
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned nper = gridDim.x >> 3;
+    const double2 zero = make_double2(0.0, 0.0);
+    int par = 0;                                   // mailbox parity, toggled every sweep (also across tiles)
+
+    // Per-tile state.  The loop below is rotated: the rows of tile i+1 are requested right after the stores of tile i, and
+    // the dictionary is loaded BETWEEN the first tile's row requests and its first use, so that the two global round trips
+    // overlap (one 1024^2 image is a single tile per workgroup: ~1 us of ~12).
+    unsigned bt = 0;
+    int row_lo = 0, row_hi = 0, ry0 = 0, ry1 = 0, w0 = 0, col = 0;
+    bool st_x = false, wall = false;
+    double2 xr[R];
+    unsigned cc[R];
+    // geometry of tile kk and the burst of loads for its rows: R rows of x (16 B per lane) and their codes (4 B per lane),
+    // issued unconditionally at a clamped address and selected afterwards (see tb_strip).  false: no such tile / frozen image.
+    auto open_tile = [&](const unsigned kk) __attribute__((always_inline)) -> bool {
+        bt = xcd * per + kk;
+        if (bt >= total) return false;             // workgroup-uniform, like every test up to the sweeps
+        const int tx = xmajor ? (int)(bt % (unsigned)ntx) : (int)(bt / (unsigned)gy);
+        const int bty = xmajor ? (int)(bt / (unsigned)ntx) : (int)(bt % (unsigned)gy);
+        const int img = bty / cpi;
+        if (active && !active[img]) return false;  // frozen image of a batch
+        row_lo = dom_lo + img * img_stride;
+        row_hi = row_lo + ny;
+        const int own0 = own_lo + img * img_stride;
+        ry0 = own0 + (bty - img * cpi) * ly;
+        ry1 = min(ry0 + ly, own0 + own_h);
+        w0 = ry0 - T + wave * R;                   // this wave's first array row
+        // rows worth loading: the tile's own rows + T above and below, inside the mesh
+        const int ld_lo = max(ry0 - T, row_lo), ld_hi = min(ry1 + T, row_hi);
+        // columns: exactly tb_strip's placement
+        col = tx * WOUT - shift + 2 * lane;
+        const bool in_x = col >= 0 && col < nx;
+        const int out_lo = (tx == 0) ? 0 : tx * WOUT - shift + HW;
+        const int out_hi = (tx == ntx - 1) ? nx : tx * WOUT - shift + TB_COLS - HW;
+        st_x = in_x && (col >= out_lo) && (col < out_hi);
+        wall = allb || tx == 0 || tx == ntx - 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int rr = w0 + r;
+            const bool ok = in_x && rr >= ld_lo && rr < ld_hi;
+            const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col : 0);
+            const double2 vx = ld2(x + p);
+            const unsigned vc = *reinterpret_cast<const uint32_t *>(code + p);
+            xr[r] = ok ? vx : zero;
+            cc[r] = ok ? vc : 0u;                  // outside the mesh: the zero row
+        }
+        return true;
+    };
+
+    unsigned kk = blockIdx.x >> 3;
+    bool valid = kk < per && open_tile(kk);
+    load_lut<NW * 64>(lut, lut_g, nrows);
+    t_lut = stamps ? wall_clock64() : 0ull;
+
+    while (kk < per) {
+        if (valid) {
+        unsigned long long *st = (stamps && threadIdx.x == 0) ? stamps + (size_t)bt * (T + 4) : nullptr;
+        if (st) {
+            st[0] = t_entry;
+            st[1] = t_lut;
+            asm volatile("" :: "v"(xr[0].x), "v"(xr[R - 1].y), "v"(cc[R - 1]));    // wait for the first wave's rows
+            st[2] = wall_clock64();
+        }
+
+        // The T sweeps of this wave's R rows, in place, from coefficients held in registers for the whole pass.  Per sweep:
+        // publish the first and last row; update the interior rows 1 .. R-2 (they need nothing from another wave), two at a
+        // time; barrier; update rows 0 and R-1 from the neighbours' edge rows.  A wave some of whose rows no owned cell
+        // depends on any more (the tile's outermost waves) takes the row-by-row path with a wave-uniform test per row.
+        auto tile = [&](auto wall_tag) __attribute__((always_inline)) {
+            constexpr bool WALL = decltype(wall_tag)::value;
+            WgtCoef k[R];
+            double2 bb[WALL ? R : 1];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                double2 b_;
+                wgt_lookup<WALL>(lut, cc[r], k[r], b_);
+                if constexpr (WALL) bb[r] = b_;
+            }
+            auto one = [&](const int r, const double2 n_, const double2 c_, const double2 s_) __attribute__((always_inline)) {
+                const WgtCoef *const kp[1] = {&k[r]};
+                const double2 b1[1] = {WALL ? bb[WALL ? r : 0] : zero};
+                const double2 n1[1] = {n_}, c1[1] = {c_}, s1[1] = {s_};
+                double2 o[1];
+                wgt_rows<1, GUARD, FMA>(kp, b1, n1, c1, s1, omw, o);
+                return o[0];
+            };
+            auto two = [&](const int ra, const int rb, const double2 na, const double2 ca, const double2 sa, const double2 nb,
+                           const double2 cb, const double2 sb, double2 &oa, double2 &ob) __attribute__((always_inline)) {
+                const WgtCoef *const kp[2] = {&k[ra], &k[rb]};
+                const double2 b2[2] = {WALL ? bb[WALL ? ra : 0] : zero, WALL ? bb[WALL ? rb : 0] : zero};
+                const double2 n2[2] = {na, nb}, c2[2] = {ca, cb}, s2[2] = {sa, sb};
+                double2 o[2];
+                wgt_rows<2, GUARD, FMA>(kp, b2, n2, c2, s2, omw, o);
+                oa = o[0];
+                ob = o[1];
+            };
+#pragma unroll 1
+            for (int t = 1; t <= T; ++t) {
+                // level t is needed on [ry0 - (T - t), ry1 + (T - t)) inside the mesh
+                const int need_lo = max(ry0 - (T - t), row_lo), need_hi = min(ry1 + (T - t), row_hi);
+                edge[par][wave][0][lane] = xr[0];
+                edge[par][wave][1][lane] = xr[R - 1];
+                const bool any = w0 + R > need_lo && w0 < need_hi;
+                const bool full = w0 >= need_lo && w0 + R <= need_hi;
+                if (full) {
+                    const double2 old1 = xr[1], oldp = xr[R - 2];
+                    double2 prev = xr[0];
+#pragma unroll
+                    for (int r = 1; r + 1 <= R - 2; r += 2) {
+                        const double2 ca = xr[r], cb = xr[r + 1];
+                        two(r, r + 1, prev, ca, cb, ca, cb, xr[r + 2], xr[r], xr[r + 1]);
+                        prev = cb;
+                    }
+                    if constexpr ((R - 2) % 2 == 1) xr[R - 2] = one(R - 2, prev, xr[R - 2], xr[R - 1]);
+                    __syncthreads();
+                    const double2 top = (wave > 0) ? edge[par][wave - 1][1][lane] : zero;
+                    const double2 bot = (wave < NW - 1) ? edge[par][wave + 1][0][lane] : zero;
+                    two(0, R - 1, top, xr[0], old1, oldp, xr[R - 1], bot, xr[0], xr[R - 1]);
+                } else if (any) {
+                    const double2 old1 = xr[1], oldp = xr[R - 2];
+                    double2 prev = xr[0];
+#pragma unroll
+                    for (int r = 1; r <= R - 2; ++r) {
+                        const double2 cur = xr[r];
+                        const int rr = w0 + r;
+                        if (rr >= need_lo && rr < need_hi) xr[r] = one(r, prev, cur, xr[r + 1]);
+                        prev = cur;
+                    }
+                    __syncthreads();
+                    const double2 top = (wave > 0) ? edge[par][wave - 1][1][lane] : zero;
+                    const double2 bot = (wave < NW - 1) ? edge[par][wave + 1][0][lane] : zero;
+                    if (w0 >= need_lo && w0 < need_hi) xr[0] = one(0, top, xr[0], old1);
+                    if (w0 + R - 1 >= need_lo && w0 + R - 1 < need_hi) xr[R - 1] = one(R - 1, oldp, xr[R - 1], bot);
+                } else {
+                    __syncthreads();
+                }
+                par ^= 1;
+                if (st) st[2 + t] = wall_clock64();
+            }
+        };
+        if (wall) tile(TbTag<true>{});
+        else tile(TbTag<false>{});
+
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int rr = w0 + r;
+            if (st_x && rr >= ry0 && rr < ry1) st2(xnew + (size_t)rr * nx + col, xr[r]);
+        }
+        if (st) st[T + 3] = wall_clock64();
+        }
+        kk += nper;
+        valid = kk < per && open_tile(kk);
+    }
+}
+
+}  // namespace deff

@@ -109,15 +109,28 @@ def test_launch_plan_is_reported(pkg):
         s.sweeps(12)
         p = s.plan()
         assert p["tb_T"] in (4, 6, 8) and p["tb_strips"] == 1 and p["tb_LY"] * p["tb_chunks_per_image"] >= 128
-        assert p["tb_LY"] >= p["tb_T"] and p["tb_blocks"] % 8 == 0
+        assert p["tb_LY"] >= p["tb_T"] and p["tb_blocks"] % 8 == 0 and p["tb_impl"] == 1     # stacks stream
     with pkg.Solver(1024, 1024) as s:
         s.synth_image(1, 0)
         s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
         s.init_linear(0.0, 1.0)
+        s.sweeps(16)
+        p = s.plan()
+        # ONE image below 4 Mi cells: workgroup tiles, 8 sweeps per pass, 8 waves x 7 rows, every tile resident at once
+        assert p["tb_impl"] == 2 and p["tb_T"] == 8 and p["tb_R"] == 7 and p["tb_strips"] == 9
+        assert p["tb_strips"] * p["tb_chunks_per_image"] <= 256 and p["tb_LY"] * p["tb_chunks_per_image"] >= 1024
+        s.set_tuning("tb_impl", 1)
         s.set_tuning("tb_T", 8)
         s.sweeps(16)
         p = s.plan()
-        assert p["tb_T"] == 8 and p["tb_strips"] == 9 and p["tb_LY"] >= 8      # 128 + 8 x 112 columns, no halo outside the walls
+        assert p["tb_impl"] == 1 and p["tb_T"] == 8 and p["tb_strips"] == 9 and p["tb_LY"] >= 8   # 128 + 8 x 112 columns, no halo outside the walls
+    with pkg.Solver(4096, 4096) as s:
+        s.synth_image(1, 0)
+        s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(8)
+        p = s.plan()
+        assert p["tb_impl"] == 1 and p["tb_T"] == 8 and p["tb_strips"] == 37                     # large images stream
 
 
 def test_synthetic_stack_holds_consecutive_images(pkg, oracle):
@@ -186,6 +199,7 @@ def test_temporal_blocking_vs_oracle(pkg, oracle, shape, LY, T):
     nsw = 3 * T + 3
     want = oracle.sweeps(A, b, x0, nsw)
     with pkg.Solver(nx, ny, kernel="matfree_tb") as s:
+        s.set_tuning("tb_impl", 1)                             # the streaming form (workgroup tiles: tests/test_gpu_wgtile.py)
         s.set_tuning("tb_T", T)
         s.set_tuning("tb_LY", LY)
         s.set_tuning("tb_wall_halo", (nx + ny + T) % 3)        # all three strip placements get exercised

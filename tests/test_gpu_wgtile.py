@@ -1,0 +1,180 @@
+"""The workgroup-tile form of the temporally blocked pass (csrc/kernels_wgtile.hpp: 8 waves share a tile that stays in
+registers for the T sweeps of a pass, first/last rows through an LDS mailbox, one barrier per sweep) against the CPU
+oracle: every raggedness of strips / row tiles, stacks with frozen images, row slabs, the zero-diffusivity guard, the
+contracted arithmetic.  The form is selected with the tuning knob tb_impl = 2 (1 = streaming kernel); results must be
+bit-identical to the oracle whatever the form."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import effectivediffusivityfvm_amd as p
+    return p
+
+
+def rand_mask(rng, nx, ny, p=0.5):
+    return np.where(rng.random((ny, nx)) < p, 0, 255).astype(np.uint8)
+
+
+def assert_field(got, want):
+    fin = np.isfinite(want)
+    assert np.array_equal(fin, np.isfinite(got))
+    assert np.linalg.norm(got[fin] - want[fin]) <= 1e-6 * np.linalg.norm(want[fin])
+    assert np.array_equal(got, want, equal_nan=True)
+
+
+@pytest.mark.parametrize("T", [4, 8])
+@pytest.mark.parametrize("R,LY", [(4, 0), (6, 0), (7, 0), (6, 11), (7, 5)])
+@pytest.mark.parametrize("shape", [(600, 300), (1030, 37), (130, 70), (256, 256), (122, 9), (2, 64), (498, 40), (250, 33),
+                                   (97, 41), (1001, 333)])
+def test_wgtile_sweeps_vs_oracle(pkg, oracle, shape, T, R, LY):
+    nx, ny = shape
+    rng = np.random.default_rng(nx * 7 + ny * 13 + T + R)
+    pix = rand_mask(rng, nx, ny, 0.55)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-3)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    x0 = rng.random((ny, nx))
+    nsw = 3 * T + 3
+    want = oracle.sweeps(A, b, x0, nsw)
+    with pkg.Solver(nx, ny, kernel="matfree_tb") as s:
+        s.set_tuning("tb_T", T)
+        s.set_tuning("tb_impl", 2)
+        s.set_tuning("tb_R", R)
+        s.set_tuning("tb_LY", LY)
+        s.set_tuning("tb_wall_halo", (nx + ny + T) % 3)
+        s.set_image(pix)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.set_field(x0)
+        s.sweeps(nsw)
+        p = s.plan()
+        if ny >= 8:
+            assert s.kernel_in_use() == "matfree_tb" and p["tb_impl"] == 2 and p["tb_R"] == R and p["tb_T"] == T
+            assert 1 <= p["tb_LY"] <= 8 * R - 2 * T and p["tb_LY"] * p["tb_chunks_per_image"] >= ny
+            if LY:
+                assert p["tb_LY"] <= LY
+        assert_field(s.get_field(), want)
+
+
+@pytest.mark.parametrize("T,R", [(4, 7), (8, 4), (8, 6)])
+def test_wgtile_omega_one_boundary_values_and_fma(pkg, oracle, T, R):
+    """updateX_V1's arithmetic (omega = 1), non-trivial wall values, and the contracted arithmetic against the
+    oracle's -ffp-contract=fast build."""
+    nx, ny = 300, 150
+    rng = np.random.default_rng(T * 10 + R)
+    pix = rand_mask(rng, nx, ny, 0.45)
+    D = oracle.fill_D_2phase(pix, 2.0, 0.3)
+    A, b = oracle.discretize(D, 2.0, -1.0)
+    x0 = rng.random((ny, nx))
+    for omega, kern in ((1.0, 1), (2.0 / 3.0, 0)):
+        for flavour, fma in ((None, 0), ("fma", 1)):
+            want = oracle.sweeps(A, b, x0, 2 * T + 1, kernel=kern, omega=omega, flavour=flavour)
+            with pkg.Solver(nx, ny, kernel="matfree_tb") as s:
+                s.set_tuning("tb_T", T); s.set_tuning("tb_impl", 2); s.set_tuning("tb_R", R); s.set_tuning("fma", fma)
+                s.set_image(pix)
+                s.assemble_2phase(0.3, 2.0, 2.0, -1.0)
+                s.set_field(x0)
+                s.sweeps(2 * T + 1, omega)
+                assert s.plan()["tb_impl"] == 2
+                assert_field(s.get_field(), want)
+
+
+def test_wgtile_zero_diffusivity_guard_and_three_phase(pkg, oracle, img00000):
+    """Ds = 0: -0.0 links and NaN cells (the reference's non-zero test, cuh:77) through the guarded instantiation; then
+    the as-shipped 3-phase system (harvested dictionary, right-hand side possibly away from the walls)."""
+    D = oracle.fill_D_2phase(img00000, 1.0, 0.0)
+    with np.errstate(all="ignore"):
+        A, b = oracle.discretize(D, 0.0, 1.0)
+        want = oracle.sweeps(A, b, oracle.linear_guess(128, 128, 0.0, 1.0), 19)
+    with pkg.Solver(128, 128, kernel="matfree_tb") as s:
+        s.set_tuning("tb_T", 8); s.set_tuning("tb_impl", 2)
+        s.set_image(img00000)
+        s.assemble_2phase(0.0, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(19)
+        assert s.plan()["tb_impl"] == 2
+        assert_field(s.get_field(), want)
+    grid, _ = oracle.floodfill((img00000 > 200).astype(np.uint32))
+    D3 = oracle.fill_D_3phase(img00000, 1.0, 0.0, 1237500.0)
+    with np.errstate(all="ignore"):
+        A3, b3 = oracle.discretize(D3, 0.0, 1.0, grid=grid)
+        want3 = oracle.sweeps(A3, b3, oracle.linear_guess(128, 128, 0.0, 1.0), 21)
+    for R in (4, 7):
+        with pkg.Solver(128, 128) as s:
+            s.set_tuning("tb_T", 4); s.set_tuning("tb_impl", 2); s.set_tuning("tb_R", R)
+            s.set_image(img00000)
+            s.assemble_3phase(0.0, 1.0, 1237500.0, 0.0, 1.0, grid)
+            s.init_linear(0.0, 1.0)
+            s.sweeps(21)
+            assert s.kernel_in_use() == "matfree_tb" and s.plan()["tb_impl"] == 2
+            assert_field(s.get_field(), want3)
+
+
+@pytest.mark.parametrize("shape,B", [((130, 70), 5), ((64, 9), 3), ((256, 128), 2)])
+def test_wgtile_stack_with_frozen_images(pkg, oracle, shape, B):
+    """Stacks: tiles never straddle images; a solve in which images stop at different checks (device mask)."""
+    nx, ny = shape
+    rng = np.random.default_rng(nx + B)
+    pixs = [rand_mask(rng, nx, ny, 0.35 + 0.1 * k) for k in range(B)]
+    with pkg.Solver(nx, ny, nimg=B, kernel="matfree_tb") as s:
+        s.set_tuning("tb_T", 4); s.set_tuning("tb_impl", 2); s.set_tuning("tb_R", 4)
+        s.set_image(np.stack(pixs))
+        s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        res = s.solve(1e-3, 4000, check_every=200)
+        got = s.get_field()
+        assert s.plan()["tb_impl"] == 2
+    res = res if isinstance(res, list) else [res]
+    iters = set()
+    for k in range(B):
+        D = oracle.fill_D_2phase(pixs[k], 1.0, 1e-2)
+        A, b = oracle.discretize(D, 0.0, 1.0)
+        it, deff, conv, x, _, _ = oracle.jacobi(A, b, oracle.linear_guess(nx, ny, 0.0, 1.0), D, 0.0, 1.0, 1e-3, 4000,
+                                                check_every=200)
+        assert (res[k].iters, res[k].deff_raw, res[k].conv) == (it, deff, conv)
+        assert_field(got[k * ny:(k + 1) * ny], x)
+        iters.add(it)
+    if B > 2:
+        assert len(iters) > 1                      # the device mask was exercised
+
+
+@pytest.mark.parametrize("nslabs", [2, 3])
+def test_wgtile_row_slabs(pkg, oracle, nslabs):
+    """Row slabs (halo rows above and below the owned rows, mesh rows taken from the whole image)."""
+    nx, NY = 384, 203
+    rng = np.random.default_rng(nslabs)
+    pix = rand_mask(rng, nx, NY, 0.55)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-3)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    x0 = rng.random((NY, nx))
+    want = oracle.sweeps(A, b, x0, 29)
+    with pkg.SlabGroup(nx, NY, [0] * nslabs) as g:
+        g.set_tuning("tb_T", 8); g.set_tuning("tb_impl", 2); g.set_tuning("tb_R", 4)
+        g.set_image(pix)
+        g.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        g.set_field(x0)
+        g.sweeps(29)
+        assert all(p["tb_impl"] == 2 and p["tb_T"] == 8 for p in g.plans())
+        assert_field(g.get_field(), want)
+        d, MFL, MFR = g.flux()
+        dor, MFLo, MFRo = oracle.flux_deff(want, D, 0.0, 1.0)
+        assert d == dor and np.array_equal(MFL, MFLo) and np.array_equal(MFR, MFRo)
+
+
+def test_wgtile_1024_vs_oracle(pkg, oracle):
+    """BASELINE config #2's image: 1024^2 synthetic, 27 sweeps, both forms, against the oracle."""
+    n = 1024
+    pix = oracle.synth_mask(n, n, 12345, 0)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-3)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    want = oracle.sweeps(A, b, oracle.linear_guess(n, n, 0.0, 1.0), 27)
+    for impl, T, R in ((2, 8, 7), (2, 8, 6), (2, 4, 4), (1, 4, 0), (0, 0, 0)):
+        with pkg.Solver(n, n, kernel="matfree_tb") as s:
+            s.set_tuning("tb_T", T); s.set_tuning("tb_impl", impl); s.set_tuning("tb_R", R)
+            s.synth_image(12345, 0)
+            s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            s.init_linear(0.0, 1.0)
+            s.sweeps(27)
+            assert_field(s.get_field(), want)

@@ -43,7 +43,7 @@ def main():
             pl = s.plan()
             print(f"n={n:6d} {var:40s} med {med*1e3:9.2f} us  min {best*1e3:9.2f} us  "
                   f"{rate:10.0f} Mcells*iter/s  frac@64B {rate*64/8e6:.3f}  "
-                  f"T={pl['tb_T']} LY={pl['tb_LY']} strips={pl['tb_strips']} cpi={pl['tb_chunks_per_image']}", flush=True)
+                  f"T={pl['tb_T']} LY={pl['tb_LY']} strips={pl['tb_strips']} cpi={pl['tb_chunks_per_image']} impl={pl['tb_impl']} R={pl['tb_R']} NW={pl['tb_NW']} wg={pl['tb_blocks']}", flush=True)
             s.close()
 
 
