@@ -68,8 +68,56 @@ def cpu_baseline(n, seconds_target=12.0):
                        f"host has {os.cpu_count()} logical CPUs"}, k + 2, x)
 
 
+def bench_slab_one_gpu(args, pkg, torch, local_rank):
+    """--mode slab --slabs N on ONE GPU: the same image as N row slabs driven by one process (peer copies between the
+    slabs' buffers), with the exchange overlapped with the interior of the pass and without, next to the unsplit context.
+    The slabs share the GPU, so this measures what the slab machinery and the exposed part of the exchange COST per pass,
+    not a speed-up."""
+    n, S, N = args.size, args.sweeps_per_step, args.slabs
+    out = {}
+
+    def run(obj):
+        for _ in range(args.warmup):
+            obj.sweeps(S, args.omega)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            obj.sweeps(S, args.omega)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.steps
+
+    with pkg.Solver(n, n, device=local_rank) as s:
+        s.synth_image(12345, 0)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        out["one_context"] = run(s)
+        launches, T = s.last_launches()
+    for tag, ov in (("slabs_overlap", 1), ("slabs_serial", 0)):
+        with pkg.SlabGroup(n, n, [local_rank] * N) as g:
+            g.set_tuning("slab_overlap", ov)
+            g.synth_image(12345, 0)
+            g.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            g.init_linear(0.0, 1.0)
+            out[tag] = run(g)
+    passes = S // T + S % T
+    cells = float(n) * n
+    print(json.dumps({
+        "metric": f"Mcells*iter/s (Jacobi sweep) at {n}^2, {N} row slabs on one GPU", "value": cells * S / out["slabs_overlap"] / 1e6,
+        "unit": "Mcells*iter/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": out["slabs_overlap"] * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"ONE {n}x{n} synthetic two-phase image as {N} row slabs on one GPU (one process, peer copies), "
+                               f"8-row halos, one exchange per pass of {T} sweeps; step = {S} sweeps", "sweeps_per_step": S},
+        "per_pass_us": {k: v / passes * 1e6 for k, v in out.items()},
+        "exchange_exposed_us_per_pass": {"overlapped": (out["slabs_overlap"] - out["one_context"]) / passes * 1e6,
+                                         "serial": (out["slabs_serial"] - out["one_context"]) / passes * 1e6},
+        "Mcells_iter_per_s": {k: cells * S / v / 1e6 for k, v in out.items()}}), flush=True)
+
+
 def bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier, use_dist):
     """One --size x --size image split into `world` row slabs (RCCL halo exchange per blocked pass)."""
+    if world == 1 and args.slabs > 1:
+        return bench_slab_one_gpu(args, pkg, torch, local_rank)
     n, S = args.size, args.sweeps_per_step
     uid = [pkg.rccl_unique_id() if rank == 0 else None]
     if use_dist:
@@ -91,13 +139,17 @@ def bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier, use_dis
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        elapsed = max(float(t.item()) for t in every)
     if rank == 0:
         cells = float(n) * n
         print(json.dumps({
+            "per_rank_ms_per_step": per_rank_ms,
             "metric": f"Mcells*iter/s (Jacobi sweep) at {n}^2, row slabs", "value": cells * S * args.steps / elapsed / 1e6,
             "unit": "Mcells*iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -127,6 +179,8 @@ def main():
                     help="images: one image per GPU, no collective (default, weak scaling); slab: ONE image of "
                          "--size rows split into row slabs over the GPUs with RCCL halo exchange (config #4, strong)")
     ap.add_argument("--batch", type=int, default=1, help="images per GPU swept together (dataset-generation mode)")
+    ap.add_argument("--slabs", type=int, default=1, help="--mode slab on ONE GPU: split the image into this many slabs "
+                                                         "(one process, peer copies) and report the exchange's exposed time")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,6 +273,18 @@ def main():
         s.sweeps(sweeps_per_launch * 4, args.omega)
         fma_ms = s.sweeps(S, args.omega)
         s.set_tuning("fma", 0)
+
+    # fourth reported row: BASELINE config #2's shape -- ONE 1024^2 image (too few cells to fill the chip with one wave
+    # per tile: the planner switches to workgroup tiles, kernels_wgtile.hpp); same physics, its own small context
+    small = None
+    if rank == 0 and n != 1024 and args.batch == 1:
+        with pkg.Solver(1024, 1024, device=local_rank, kernel=args.kernel) as s2:
+            s2.synth_image(12345, 0)
+            s2.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            s2.init_linear(0.0, 1.0)
+            s2.sweeps(960, args.omega)
+            ms2 = min(s2.sweeps(4800, args.omega) for _ in range(3))
+            small = (1024.0 * 1024.0 * 4800 / (ms2 * 1e-3) / 1e6, s2.kernel_in_use(), s2.plan())
 
     if rank == 0:
         cells = float(n) * n * args.batch
@@ -321,6 +387,10 @@ def main():
             if kernel_used == "matfree_tb":
                 fl = FP64_INSTR_PER_CELL[True] * cells * S / (fma_ms * 1e-3) / 1e12
                 out["contracted_arithmetic"]["fp64_instr_frac"] = fl / FP64_INSTR_PEAK_T
+        if small:
+            out["single_image_1024"] = {"value": small[0], "unit": "Mcells*iter/s", "kernel": small[1], "plan": small[2],
+                                        "sample": "4800 sweeps (best of 3) of ONE 1024x1024 synthetic image (BASELINE config #2's "
+                                                  "shape), same physics, one GPU"}
         if world == 1 and not args.no_cpu_baseline:
             base, K, want = cpu_baseline(n)
             out["cpu_baseline"] = base

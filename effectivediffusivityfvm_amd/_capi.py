@@ -27,7 +27,7 @@ SYMBOLS = [
     "deff_slab_group_init_linear", "deff_slab_group_set_field", "deff_slab_group_get_field",
     "deff_slab_group_sweeps", "deff_slab_group_flux", "deff_slab_group_solve",
     "deff_rccl_unique_id", "deff_slab_rank_create", "deff_slab_rank_create_custom", "deff_slab_rank_destroy", "deff_slab_rank_layout",
-    "deff_slab_rank_window", "deff_slab_rank_context", "deff_slab_rank_set_image_window",
+    "deff_slab_rank_window", "deff_slab_rank_context", "deff_slab_rank_set_tuning", "deff_slab_rank_set_image_window",
     "deff_slab_rank_synth_image", "deff_slab_rank_assemble_3phase", "deff_slab_group_assemble_3phase", "deff_slab_rank_get_field", "deff_slab_rank_sweeps", "deff_slab_rank_solve",
     "deff_solve_stream", "deff_get_slot_field", "deff_debug_tb_stamps", "deff_flux", "deff_set_progress", "deff_last_launches", "deff_device_field", "deff_synchronize",
 ]
@@ -112,6 +112,7 @@ def load():
     L.deff_slab_group_destroy.argtypes = [ctx]
     L.deff_slab_group_layout.argtypes = [ctx, ip, ip]
     L.deff_slab_group_set_tuning.argtypes = [ctx, C.c_char_p, C.c_int]
+    L.deff_slab_rank_set_tuning.argtypes = [ctx, C.c_char_p, C.c_int]
     L.deff_slab_group_get_plan.argtypes = [ctx, C.c_int, C.c_char_p, C.POINTER(C.c_int)]
     L.deff_slab_group_set_image.argtypes = [ctx, _u8p]
     L.deff_slab_group_synth_image.argtypes = [ctx, C.c_uint64, C.c_uint64]

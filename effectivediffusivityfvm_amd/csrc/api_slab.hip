@@ -28,8 +28,62 @@ struct deff_slab_group {
     std::vector<deff_ctx *> ctx;
     std::vector<int> g0, own;                 // first global row and row count of every slab
     std::vector<hipEvent_t> done;             // "pass finished" per slab
+    // overlap of the exchange with the interior of the pass: per slab a second stream for the copies and two events --
+    // bnd: "the rows my neighbours wait for (first / last SLAB_HALO owned rows) are written", halo: "my halo rows hold
+    // the neighbours' new rows"
+    std::vector<hipStream_t> xs;
+    std::vector<hipEvent_t> bnd, halo;
+    int overlap = 1;
     std::vector<double> mfl, mfr;             // global wall fluxes of the last check
 };
+
+// The launch plans of one slab's pass: the whole slab in one launch, or -- so that the exchange can start while most of
+// the slab is still being swept -- the two SLAB_HALO-row bands the neighbours wait for, then the interior.
+struct SlabPass {
+    SweepPlan whole, top, bot, mid;
+    bool split = false;
+};
+
+static int slab_pass_plans(deff_ctx *c, double omega, int T_override, bool overlap, SlabPass *sp)
+{
+    sp->whole = SweepPlan();
+    sp->whole.T_override = T_override;
+    TRY(plan_sweeps(c, omega, &sp->whole));
+    if (sp->whole.kernel != DEFF_KERNEL_MATFREE_TB) return fail(DEFF_ESTATE, "row-slab mode needs the temporally blocked kernel");
+    sp->split = overlap && c->own_h >= 3 * SLAB_HALO;
+    if (!sp->split) return DEFF_OK;
+    const int lo[3] = {c->own_lo, c->own_lo + c->own_h - SLAB_HALO, c->own_lo + SLAB_HALO};
+    const int h[3] = {SLAB_HALO, SLAB_HALO, c->own_h - 2 * SLAB_HALO};
+    SweepPlan *pl[3] = {&sp->top, &sp->bot, &sp->mid};
+    for (int k = 0; k < 3; ++k) {
+        *pl[k] = SweepPlan();
+        pl[k]->T_override = sp->whole.T;       // the same sweeps per pass as the whole-slab plan
+        pl[k]->band_lo = lo[k];
+        pl[k]->band_h = h[k];
+        TRY(plan_sweeps(c, omega, pl[k]));
+    }
+    return DEFF_OK;
+}
+
+// Enqueue one pass of a slab on its stream: the bands first (then `bnd`), the interior behind them; flips x[cur].
+static int slab_enqueue_pass(deff_ctx *c, const SlabPass &sp, hipEvent_t bnd)
+{
+    if (sp.split) {
+        launch_tb_pass(c, sp.top);
+        launch_tb_pass(c, sp.bot);
+        HIP_TRY(hipEventRecord(bnd, c->stream));
+        launch_tb_pass(c, sp.mid);
+        c->last_launches += 3;
+    } else {
+        launch_tb_pass(c, sp.whole);
+        HIP_TRY(hipEventRecord(bnd, c->stream));
+        ++c->last_launches;
+    }
+    c->cur ^= 1;
+    HIP_TRY(hipGetLastError());
+    return DEFF_OK;
+}
+
 
 static int slab_create_ctx(int device, int nx, int NY, int nslabs, int g0, int own, deff_ctx **out)
 {
@@ -66,10 +120,14 @@ try {
         rc = slab_create_ctx(devices ? devices[r] : 0, nx, NY, nslabs, a, b - a, &c);
         if (rc != DEFF_OK) break;
         g->ctx.push_back(c); g->g0.push_back(a); g->own.push_back(b - a);
-        hipEvent_t ev = nullptr;
-        if (hipSetDevice(c->device) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
-            rc = fail(DEFF_EHIP, "event creation failed");
-        g->done.push_back(ev);
+        hipEvent_t ev = nullptr, eb = nullptr, eh = nullptr;
+        hipStream_t xs = nullptr;
+        if (hipSetDevice(c->device) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&eh, hipEventDisableTiming) != hipSuccess ||
+            hipStreamCreateWithFlags(&xs, hipStreamNonBlocking) != hipSuccess)
+            rc = fail(DEFF_EHIP, "event / stream creation failed");
+        g->done.push_back(ev); g->bnd.push_back(eb); g->halo.push_back(eh); g->xs.push_back(xs);
     }
     if (rc != DEFF_OK) { deff_slab_group_destroy(g); return rc; }
     // direct xGMI copies between neighbouring slabs' devices (staged through the host otherwise)
@@ -92,7 +150,11 @@ extern "C" int deff_slab_group_destroy(deff_slab_group *g)
 try {
     if (!g) return DEFF_OK;
     for (size_t r = 0; r < g->ctx.size(); ++r) {
-        if (r < g->done.size() && g->done[r]) { (void)hipSetDevice(g->ctx[r]->device); (void)hipEventDestroy(g->done[r]); }
+        (void)hipSetDevice(g->ctx[r]->device);
+        if (r < g->xs.size() && g->xs[r]) { (void)hipStreamSynchronize(g->xs[r]); (void)hipStreamDestroy(g->xs[r]); }
+        if (r < g->done.size() && g->done[r]) (void)hipEventDestroy(g->done[r]);
+        if (r < g->bnd.size() && g->bnd[r]) (void)hipEventDestroy(g->bnd[r]);
+        if (r < g->halo.size() && g->halo[r]) (void)hipEventDestroy(g->halo[r]);
         deff_destroy(g->ctx[r]);
     }
     delete g;
@@ -234,80 +296,75 @@ try {
 }
 DEFF_API_CATCH
 
-// After a pass: every slab's halo rows of the NEW field are stale; refill them from the
-// neighbours' own rows.  Copies run on the receiver's stream once the sender's pass is done.
-static int slab_exchange(deff_slab_group *g)
+// One pass over all slabs.  Per slab r, on its own stream: wait until its halo rows are valid (`halo[r]`, recorded by the
+// previous pass's copies), sweep the two bands its neighbours wait for, record `bnd[r]`, sweep the interior.  On the slab's
+// copy stream xs[r]: wait for the neighbours' `bnd`, copy their new boundary rows into this slab's halo rows of the NEW
+// field (hipMemcpyPeerAsync: xGMI between devices), record `halo[r]`.  So the copies of pass p run while the interiors of
+// pass p are still being swept, and pass p+1 of a slab starts as soon as ITS halos are in -- no global synchronisation.
+// Buffer reuse is safe by transitivity: a slab overwrites the rows a neighbour copied from two passes later, and it cannot
+// get there before that neighbour recorded the `bnd` of the pass in between, which it does only after its copies finished.
+static int slab_pass(deff_slab_group *g, std::vector<SlabPass> &sp)
 {
     const size_t blk = (size_t)SLAB_HALO * g->nx;                      // doubles per halo block
     for (int r = 0; r < g->n; ++r) {
-        TRY(use_device(g->ctx[r]));
-        HIP_TRY(hipEventRecord(g->done[r], g->ctx[r]->stream));
+        deff_ctx *c = g->ctx[r];
+        TRY(use_device(c));
+        HIP_TRY(hipStreamWaitEvent(c->stream, g->halo[r], 0));         // never recorded yet: returns at once
+        TRY(slab_enqueue_pass(c, sp[r], g->bnd[r]));
     }
     for (int r = 0; r < g->n; ++r) {
         deff_ctx *c = g->ctx[r];
         TRY(use_device(c));
+        hipStream_t xs = g->overlap ? g->xs[r] : c->stream;
         if (r > 0) {                                                   // top halo <- last own rows of slab r-1
             deff_ctx *u = g->ctx[r - 1];
-            HIP_TRY(hipStreamWaitEvent(c->stream, g->done[r - 1], 0));
+            HIP_TRY(hipStreamWaitEvent(xs, g->bnd[r - 1], 0));
             const double *src = u->x[u->cur] + (size_t)(u->own_lo + u->own_h - SLAB_HALO) * g->nx;
-            HIP_TRY(hipMemcpyPeerAsync(c->x[c->cur], c->device, src, u->device, sizeof(double) * blk, c->stream));
+            HIP_TRY(hipMemcpyPeerAsync(c->x[c->cur], c->device, src, u->device, sizeof(double) * blk, xs));
         }
         if (r + 1 < g->n) {                                            // bottom halo <- first own rows of slab r+1
             deff_ctx *d = g->ctx[r + 1];
-            HIP_TRY(hipStreamWaitEvent(c->stream, g->done[r + 1], 0));
+            HIP_TRY(hipStreamWaitEvent(xs, g->bnd[r + 1], 0));
             const double *src = d->x[d->cur] + (size_t)d->own_lo * g->nx;
             HIP_TRY(hipMemcpyPeerAsync(c->x[c->cur] + (size_t)(c->own_lo + c->own_h) * g->nx, c->device, src,
-                                       d->device, sizeof(double) * blk, c->stream));
+                                       d->device, sizeof(double) * blk, xs));
         }
-    }
-    // a slab must not start its next pass (which overwrites x[cur^1] ... and whose result the
-    // neighbours will read) before the neighbours have taken their copies of this one
-    for (int r = 0; r < g->n; ++r) {
-        TRY(use_device(g->ctx[r]));
-        HIP_TRY(hipEventRecord(g->done[r], g->ctx[r]->stream));
-    }
-    for (int r = 0; r < g->n; ++r) {
-        TRY(use_device(g->ctx[r]));
-        if (r > 0) HIP_TRY(hipStreamWaitEvent(g->ctx[r]->stream, g->done[r - 1], 0));
-        if (r + 1 < g->n) HIP_TRY(hipStreamWaitEvent(g->ctx[r]->stream, g->done[r + 1], 0));
+        HIP_TRY(hipEventRecord(g->halo[r], xs));
     }
     return DEFF_OK;
 }
 
 // n sweeps on every slab: blocked passes of T, remainder as T = 1 passes, one exchange per pass.
-static int slab_sweeps(deff_slab_group *g, std::vector<SweepPlan> &plT, std::vector<SweepPlan> &pl1, int64_t n)
+static int slab_sweeps(deff_slab_group *g, std::vector<SlabPass> &plT, std::vector<SlabPass> &pl1, int64_t n)
 {
-    const int T = plT[0].T;
+    const int T = plT[0].whole.T;
     while (n > 0) {
         const bool big = n >= T;
-        for (int r = 0; r < g->n; ++r) {
-            TRY(use_device(g->ctx[r]));
-            enqueue_tb_pass(g->ctx[r], big ? plT[r] : pl1[r]);
-            ++g->ctx[r]->last_launches;
-        }
-        HIP_TRY(hipGetLastError());
-        TRY(slab_exchange(g));
+        TRY(slab_pass(g, big ? plT : pl1));
         n -= big ? T : 1;
+    }
+    // whatever comes next on a slab's stream (fluxes, field download, another solve) sees complete halos
+    for (int r = 0; r < g->n; ++r) {
+        TRY(use_device(g->ctx[r]));
+        HIP_TRY(hipStreamWaitEvent(g->ctx[r]->stream, g->halo[r], 0));
     }
     return DEFF_OK;
 }
 
-static int slab_plans(deff_slab_group *g, double omega, std::vector<SweepPlan> &plT, std::vector<SweepPlan> &pl1)
+static int slab_plans(deff_slab_group *g, double omega, std::vector<SlabPass> &plT, std::vector<SlabPass> &pl1)
 {
-    plT.assign(g->n, SweepPlan()); pl1.assign(g->n, SweepPlan());
+    plT.assign(g->n, SlabPass()); pl1.assign(g->n, SlabPass());
     for (int r = 0; r < g->n; ++r) {
         deff_ctx *c = g->ctx[r];
         TRY(use_device(c));
         if (c->tb_T > SLAB_HALO) return fail(DEFF_EINVAL, "tb_T exceeds the slab halo depth %d", SLAB_HALO);
-        TRY(plan_sweeps(c, omega, &plT[r]));
-        if (plT[r].kernel != DEFF_KERNEL_MATFREE_TB) return fail(DEFF_ESTATE, "row-slab mode needs the temporally blocked kernel");
-        pl1[r].T_override = 1;
-        TRY(plan_sweeps(c, omega, &pl1[r]));
+        TRY(slab_pass_plans(c, omega, 0, g->overlap != 0, &plT[r]));
+        TRY(slab_pass_plans(c, omega, 1, g->overlap != 0, &pl1[r]));
         c->last_launches = 0;
         // all slabs of one image advance in lock-step: one T, one exchange per pass
-        if (plT[r].T != plT[0].T)
+        if (plT[r].whole.T != plT[0].whole.T)
             return fail(DEFF_ESTATE, "slab %d plans %d sweeps per pass, slab 0 plans %d: set tb_T on the group, not per slab", r,
-                        plT[r].T, plT[0].T);
+                        plT[r].whole.T, plT[0].whole.T);
     }
     return DEFF_OK;
 }
@@ -315,7 +372,7 @@ static int slab_plans(deff_slab_group *g, double omega, std::vector<SweepPlan> &
 extern "C" int deff_slab_group_sweeps(deff_slab_group *g, int64_t n, double omega, float *ms)
 try {
     if (!g || n < 0) return fail(DEFF_EINVAL, "bad arguments");
-    std::vector<SweepPlan> plT, pl1;
+    std::vector<SlabPass> plT, pl1;
     TRY(slab_plans(g, omega, plT, pl1));
     deff_ctx *c0 = g->ctx[0];
     TRY(use_device(c0));
@@ -364,7 +421,7 @@ extern "C" int deff_slab_group_solve(deff_slab_group *g, double omega, double to
 try {
     if (!g || !out) return fail(DEFF_EINVAL, "NULL argument");
     if (check_every < 1) return fail(DEFF_EINVAL, "check_every must be >= 1");
-    std::vector<SweepPlan> plT, pl1;
+    std::vector<SlabPass> plT, pl1;
     TRY(slab_plans(g, omega, plT, pl1));
     deff_ctx *c0 = g->ctx[0];
     int64_t iter = 0, checks = 0;
@@ -401,6 +458,7 @@ DEFF_API_CATCH
 extern "C" int deff_slab_group_set_tuning(deff_slab_group *g, const char *key, int value)
 try {
     if (!g) return fail(DEFF_EINVAL, "group is NULL");
+    if (key && !strcmp(key, "slab_overlap")) { g->overlap = value ? 1 : 0; return DEFF_OK; }
     for (int r = 0; r < g->n; ++r) TRY(deff_set_tuning(g->ctx[r], key, value));
     return DEFF_OK;
 }
@@ -434,6 +492,10 @@ struct deff_slab_rank {
     deff_host_allgather_fn gather = nullptr;
     void *user = nullptr;
     std::vector<double> h_send_up, h_send_dn, h_recv_up, h_recv_dn, h_pack;
+    // exchange overlapped with the interior of the pass (see slab_pass): copy / RCCL stream and the two events
+    hipStream_t xs = nullptr;
+    hipEvent_t bnd = nullptr, halo = nullptr;
+    int overlap = 1;
 };
 
 #define NCCL_TRY(expr)                                                                          \
@@ -458,6 +520,9 @@ extern "C" int deff_slab_rank_destroy(deff_slab_rank *s)
 try {
     if (!s) return DEFF_OK;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);
+    if (s->xs) { (void)hipStreamSynchronize(s->xs); (void)hipStreamDestroy(s->xs); }
+    if (s->bnd) (void)hipEventDestroy(s->bnd);
+    if (s->halo) (void)hipEventDestroy(s->halo);
     if (s->d_pack) (void)hipFree(s->d_pack);
     if (s->d_all) (void)hipFree(s->d_all);
     if (s->comm) (void)ncclCommDestroy(s->comm);
@@ -531,6 +596,10 @@ static int slab_rank_create_impl(int device, int nx, int NY, int rank, int nrank
             rc = fail(DEFF_ENOMEM, "hipMalloc: %s", hipGetErrorString(he));
         else if ((he = hipMemset(s->d_pack, 0, sizeof(double) * 2 * s->maxown)) != hipSuccess)
             rc = fail(DEFF_EHIP, "hipMemset: %s", hipGetErrorString(he));
+        else if ((he = hipStreamCreateWithFlags(&s->xs, hipStreamNonBlocking)) != hipSuccess ||
+                 (he = hipEventCreateWithFlags(&s->bnd, hipEventDisableTiming)) != hipSuccess ||
+                 (he = hipEventCreateWithFlags(&s->halo, hipEventDisableTiming)) != hipSuccess)
+            rc = fail(DEFF_EHIP, "stream / event creation failed: %s", hipGetErrorString(he));
     }
     if (rc != DEFF_OK) { deff_slab_rank_destroy(s); return rc; }
     *out = s;
@@ -552,6 +621,14 @@ try {
     if (!s || !ctx) return fail(DEFF_EINVAL, "NULL argument");
     *ctx = s->ctx;
     return DEFF_OK;
+}
+DEFF_API_CATCH
+
+extern "C" int deff_slab_rank_set_tuning(deff_slab_rank *s, const char *key, int value)
+try {
+    if (!s || !key) return fail(DEFF_EINVAL, "NULL argument");
+    if (!strcmp(key, "slab_overlap")) { s->overlap = value ? 1 : 0; return DEFF_OK; }
+    return deff_set_tuning(s->ctx, key, value);
 }
 DEFF_API_CATCH
 
@@ -635,7 +712,10 @@ try {
 }
 DEFF_API_CATCH
 
-static int rank_exchange(deff_slab_rank *s)
+// The exchange of one pass, on stream `xs` (the copy stream when overlapping, else the context's): the first / last
+// SLAB_HALO owned rows of the NEW field go to the neighbours, theirs come into the halo rows.  The caller has made `xs`
+// wait for the band kernels that write those rows.
+static int rank_exchange(deff_slab_rank *s, hipStream_t xs)
 {
     deff_ctx *c = s->ctx;
     const size_t blk = (size_t)SLAB_HALO * s->nx;
@@ -643,16 +723,16 @@ static int rank_exchange(deff_slab_rank *s)
     if (s->xchg) {                                               // host-staged custom transport
         const bool up = s->rank > 0, dn = s->rank + 1 < s->nranks;
         double *top_own = x + (size_t)c->own_lo * s->nx, *bot_own = x + (size_t)(c->own_lo + c->own_h - SLAB_HALO) * s->nx;
-        if (up) HIP_TRY(hipMemcpyAsync(s->h_send_up.data(), top_own, sizeof(double) * blk, hipMemcpyDeviceToHost, c->stream));
-        if (dn) HIP_TRY(hipMemcpyAsync(s->h_send_dn.data(), bot_own, sizeof(double) * blk, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (up) HIP_TRY(hipMemcpyAsync(s->h_send_up.data(), top_own, sizeof(double) * blk, hipMemcpyDeviceToHost, xs));
+        if (dn) HIP_TRY(hipMemcpyAsync(s->h_send_dn.data(), bot_own, sizeof(double) * blk, hipMemcpyDeviceToHost, xs));
+        HIP_TRY(hipStreamSynchronize(xs));                       // the interior of the pass keeps running on the other stream
         if (s->xchg(s->user, up ? s->h_send_up.data() : nullptr, up ? s->h_recv_up.data() : nullptr,
                     dn ? s->h_send_dn.data() : nullptr, dn ? s->h_recv_dn.data() : nullptr, blk) != 0)
             return fail(DEFF_ECOMM, "custom halo exchange failed");
-        if (up) HIP_TRY(hipMemcpyAsync(x, s->h_recv_up.data(), sizeof(double) * blk, hipMemcpyHostToDevice, c->stream));
+        if (up) HIP_TRY(hipMemcpyAsync(x, s->h_recv_up.data(), sizeof(double) * blk, hipMemcpyHostToDevice, xs));
         if (dn) HIP_TRY(hipMemcpyAsync(x + (size_t)(c->own_lo + c->own_h) * s->nx, s->h_recv_dn.data(), sizeof(double) * blk,
-                                       hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));                // the host buffers are reused by the next pass
+                                       hipMemcpyHostToDevice, xs));
+        HIP_TRY(hipStreamSynchronize(xs));                       // the host buffers are reused by the next pass
         return DEFF_OK;
     }
     // a failure between GroupStart and GroupEnd must still close the group, or every later collective
@@ -662,13 +742,13 @@ static int rank_exchange(deff_slab_rank *s)
     const char *what = "";
     auto step = [&](ncclResult_t r, const char *name) { if (first == ncclSuccess && r != ncclSuccess) { first = r; what = name; } };
     if (s->rank > 0) {
-        step(ncclSend(x + (size_t)c->own_lo * s->nx, blk, ncclDouble, s->rank - 1, s->comm, c->stream), "ncclSend(up)");
-        step(ncclRecv(x, blk, ncclDouble, s->rank - 1, s->comm, c->stream), "ncclRecv(up)");
+        step(ncclSend(x + (size_t)c->own_lo * s->nx, blk, ncclDouble, s->rank - 1, s->comm, xs), "ncclSend(up)");
+        step(ncclRecv(x, blk, ncclDouble, s->rank - 1, s->comm, xs), "ncclRecv(up)");
     }
     if (s->rank + 1 < s->nranks) {
-        step(ncclSend(x + (size_t)(c->own_lo + c->own_h - SLAB_HALO) * s->nx, blk, ncclDouble, s->rank + 1, s->comm, c->stream),
+        step(ncclSend(x + (size_t)(c->own_lo + c->own_h - SLAB_HALO) * s->nx, blk, ncclDouble, s->rank + 1, s->comm, xs),
              "ncclSend(down)");
-        step(ncclRecv(x + (size_t)(c->own_lo + c->own_h) * s->nx, blk, ncclDouble, s->rank + 1, s->comm, c->stream), "ncclRecv(down)");
+        step(ncclRecv(x + (size_t)(c->own_lo + c->own_h) * s->nx, blk, ncclDouble, s->rank + 1, s->comm, xs), "ncclRecv(down)");
     }
     const ncclResult_t end = ncclGroupEnd();
     if (first != ncclSuccess) return fail(DEFF_ECOMM, "%s failed: %s", what, ncclGetErrorString(first));
@@ -676,29 +756,34 @@ static int rank_exchange(deff_slab_rank *s)
     return DEFF_OK;
 }
 
-static int rank_sweeps(deff_slab_rank *s, const SweepPlan &plT, const SweepPlan &pl1, int64_t n)
+// n sweeps of this rank's slab: per pass the two boundary bands, then -- while the interior is swept on the context's
+// stream -- the exchange on the copy stream; the next pass waits for the halos only (see slab_pass for the argument).
+static int rank_sweeps(deff_slab_rank *s, const SlabPass &plT, const SlabPass &pl1, int64_t n)
 {
     deff_ctx *c = s->ctx;
+    hipStream_t xs = s->overlap ? s->xs : c->stream;
     while (n > 0) {
-        const bool big = n >= plT.T;
-        enqueue_tb_pass(c, big ? plT : pl1);
-        ++c->last_launches;
-        HIP_TRY(hipGetLastError());
-        if (s->nranks > 1) TRY(rank_exchange(s));
-        n -= big ? plT.T : 1;
+        const bool big = n >= plT.whole.T;
+        HIP_TRY(hipStreamWaitEvent(c->stream, s->halo, 0));
+        TRY(slab_enqueue_pass(c, big ? plT : pl1, s->bnd));
+        if (s->nranks > 1) {
+            HIP_TRY(hipStreamWaitEvent(xs, s->bnd, 0));
+            TRY(rank_exchange(s, xs));
+            HIP_TRY(hipEventRecord(s->halo, xs));
+        }
+        n -= big ? plT.whole.T : 1;
     }
+    HIP_TRY(hipStreamWaitEvent(c->stream, s->halo, 0));
     return DEFF_OK;
 }
 
-static int rank_plans(deff_slab_rank *s, double omega, SweepPlan *plT, SweepPlan *pl1)
+static int rank_plans(deff_slab_rank *s, double omega, SlabPass *plT, SlabPass *pl1)
 {
     deff_ctx *c = s->ctx;
     TRY(use_device(c));
     if (c->tb_T > SLAB_HALO) return fail(DEFF_EINVAL, "tb_T exceeds the slab halo depth %d", SLAB_HALO);
-    TRY(plan_sweeps(c, omega, plT));
-    if (plT->kernel != DEFF_KERNEL_MATFREE_TB) return fail(DEFF_ESTATE, "row-slab mode needs the temporally blocked kernel");
-    pl1->T_override = 1;
-    TRY(plan_sweeps(c, omega, pl1));
+    TRY(slab_pass_plans(c, omega, 0, s->overlap != 0 && s->nranks > 1, plT));
+    TRY(slab_pass_plans(c, omega, 1, s->overlap != 0 && s->nranks > 1, pl1));
     c->last_launches = 0;
     return DEFF_OK;
 }
@@ -706,7 +791,7 @@ static int rank_plans(deff_slab_rank *s, double omega, SweepPlan *plT, SweepPlan
 extern "C" int deff_slab_rank_sweeps(deff_slab_rank *s, int64_t n, double omega, float *ms)
 try {
     if (!s || n < 0) return fail(DEFF_EINVAL, "bad arguments");
-    SweepPlan plT, pl1;
+    SlabPass plT, pl1;
     TRY(rank_plans(s, omega, &plT, &pl1));
     deff_ctx *c = s->ctx;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
@@ -765,7 +850,7 @@ extern "C" int deff_slab_rank_solve(deff_slab_rank *s, double omega, double tol,
 try {
     if (!s || !out) return fail(DEFF_EINVAL, "NULL argument");
     if (check_every < 1) return fail(DEFF_EINVAL, "check_every must be >= 1");
-    SweepPlan plT, pl1;
+    SlabPass plT, pl1;
     TRY(rank_plans(s, omega, &plT, &pl1));
     deff_ctx *c = s->ctx;
     int64_t iter = 0, checks = 0;

@@ -211,6 +211,12 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             int T = pl->T_override ? pl->T_override : (c->tb_T ? c->tb_T : default_tb_T(c));
             T = clamp_tb_T(T);
             pl->T = T;
+            // rows this plan updates: the context's owned rows, or a band of them (row slabs split a pass into the
+            // bands the neighbours wait for and the interior, api_slab.hip)
+            const int own_lo = pl->band_h > 0 ? pl->band_lo : c->own_lo;
+            const int own_h = pl->band_h > 0 ? pl->band_h : c->own_h;
+            pl->own_lo = own_lo;
+            pl->own_h = own_h;
             // strips of 128 columns overlapping by 2*HW; a mesh wall needs no halo (kernels_tb.hpp)
             const int hw = (T + 1) & ~1, wout = TB_COLS - 2 * hw;
             // placement A: every strip carries its halo, also outside the first column; placement B:
@@ -239,17 +245,17 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
                         if (lymax < 1) continue;
                         int res = resident;
                         if (!res) TRY(wgt_resident_blocks(c, T, R, pl->fma, c->lut_guard, &res));
-                        const long tiles = (long)pl->ntx * ((c->own_h + lymax - 1) / lymax) * c->nimg;
+                        const long tiles = (long)pl->ntx * ((own_h + lymax - 1) / lymax) * c->nimg;
                         if (tiles <= res) { pl->R = R; break; }
                     }
                 }
                 pl->NW = WGT_WAVES;
                 const int lymax = wgt_rows_owned(T, pl->R);
                 // rows a tile owns: at most 8R - 2T; spread the image's rows evenly over its row tiles
-                int cpi = (c->own_h + lymax - 1) / lymax;
-                if (c->tb_LY > 0 && c->tb_LY < lymax) cpi = (c->own_h + c->tb_LY - 1) / c->tb_LY;
-                pl->LY = (c->own_h + cpi - 1) / cpi;
-                pl->tcpi = (c->own_h + pl->LY - 1) / pl->LY;
+                int cpi = (own_h + lymax - 1) / lymax;
+                if (c->tb_LY > 0 && c->tb_LY < lymax) cpi = (own_h + c->tb_LY - 1) / c->tb_LY;
+                pl->LY = (own_h + cpi - 1) / cpi;
+                pl->tcpi = (own_h + pl->LY - 1) / pl->LY;
                 pl->tgy = pl->tcpi * c->nimg;
                 const long tiles = (long)pl->ntx * pl->tgy;
                 if (!resident) TRY(wgt_resident_blocks(c, T, pl->R, pl->fma, c->lut_guard, &resident));
@@ -257,8 +263,10 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
                 pl->tblocks = (int)(((tiles + 7) / 8) * 8);
                 if (pl->tblocks > resident) pl->tblocks = resident >= 8 ? resident / 8 * 8 : 8;
                 pl->guard = c->lut_guard;
-                c->plan_T = pl->T; c->plan_LY = pl->LY; c->plan_ntx = pl->ntx; c->plan_cpi = pl->tcpi;
-                c->plan_blocks = pl->tblocks; c->plan_impl = 2; c->plan_R = pl->R; c->plan_NW = pl->NW;
+                if (pl->band_h <= 0) {
+                    c->plan_T = pl->T; c->plan_LY = pl->LY; c->plan_ntx = pl->ntx; c->plan_cpi = pl->tcpi;
+                    c->plan_blocks = pl->tblocks; c->plan_impl = 2; c->plan_R = pl->R; c->plan_NW = pl->NW;
+                }
             } else {
             pl->impl = 1;
             // Rows per chunk.  Workgroups are persistent, so a pass takes `rounds` tiles per wave slot
@@ -273,29 +281,29 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             int LY = c->tb_LY;
             if (!LY) {
                 long best_cost = -1;
-                const bool top_wall = c->own_lo == 0;              // not a slab with rows above it
+                const bool top_wall = own_lo == 0;              // not a slab with rows above it
                 for (int k = 1; k <= 8; ++k) {
                     const int cpi_max = (int)(((long)k * resident * 4) / ((long)pl->ntx * c->nimg));
                     if (cpi_max < 1) continue;
-                    int ly = (c->own_h + cpi_max - 1) / cpi_max;
+                    int ly = (own_h + cpi_max - 1) / cpi_max;
                     // chunks shorter than the pipeline is deep lose more to fill/drain than the model
                     // says (1024^2, T=4: 3-row chunks 254 G, 4..6-row chunks 295 G cells*iter/s)
                     if (ly < T) ly = T;
-                    const int cpi = (c->own_h + ly - 1) / ly;
+                    const int cpi = (own_h + ly - 1) / ly;
                     const long cost = (long)k * (ly + T + ((cpi > 1 || !top_wall) ? T : 0) + 8);
                     if (best_cost < 0 || cost < best_cost) { best_cost = cost; LY = ly; }
                 }
-                if (!LY) LY = c->own_h;
+                if (!LY) LY = own_h;
             }
-            if (LY > c->own_h) LY = c->own_h;
+            if (LY > own_h) LY = own_h;
             pl->LY = LY;
-            pl->tcpi = (c->own_h + LY - 1) / LY;
+            pl->tcpi = (own_h + LY - 1) / LY;
             pl->tgy = pl->tcpi * c->nimg;
             pl->tgx = (int)(((long)pl->ntx * pl->tgy + 3) / 4);       // workgroup tiles (4 wave tiles each)
             const unsigned total = (unsigned)pl->tgx;
             pl->tblocks = (int)(((total + 7u) / 8u) * 8u);
             if (pl->tblocks > resident) pl->tblocks = resident >= 8 ? resident / 8 * 8 : 8;
-            if (!pl->T_override) {                       // the remainder plan of a slab (T = 1) is not "the" plan
+            if (!pl->T_override && pl->band_h <= 0) {    // the remainder plan of a slab (T = 1) and band plans are not "the" plan
                 c->plan_T = pl->T; c->plan_LY = pl->LY; c->plan_ntx = pl->ntx; c->plan_cpi = pl->tcpi;
                 c->plan_blocks = pl->tblocks; c->plan_impl = 1; c->plan_R = 0;
             }
@@ -382,6 +390,13 @@ void enqueue_sweep(deff_ctx *c, const SweepPlan &pl)
 // One temporally blocked pass: T sweeps, x[cur] -> x[cur^1].
 void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl)
 {
+    launch_tb_pass(c, pl);
+    c->cur ^= 1;
+}
+
+// The launch of a pass (or of one band of it: pl.own_lo / pl.own_h) without the buffer flip.
+void launch_tb_pass(deff_ctx *c, const SweepPlan &pl)
+{
     const double *xin = c->x[c->cur];
     double *xout = c->x[c->cur ^ 1];
     const int flip = c->serpentine ? c->cur : 0;
@@ -389,23 +404,21 @@ void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl)
     if (pl.impl == 2) {
 #define LAUNCH_WGT(T_, R_, C_, G_)                                                                             \
     hipLaunchKernelGGL((k_sweep_wgtile<T_, R_, C_, G_>), dim3(pl.tblocks), dim3(WGT_WAVES * 64), 0, c->stream, c->lut, \
-                       c->code, xin, xout, c->nx, c->mesh_ny, c->ny, c->dom_lo, c->own_lo, c->own_h, pl.tcpi, pl.LY, \
+                       c->code, xin, xout, c->nx, c->mesh_ny, c->ny, c->dom_lo, pl.own_lo, pl.own_h, pl.tcpi, pl.LY, \
                        mask, pl.ntx, pl.tgy, c->tb_xmajor, (c->lut_allb || c->nx != c->nxt) ? 1 : 0,         \
                        c->lut_nrows, pl.shift, pl.omw, c->tb_stamps)
         WGT_DISPATCH(pl.T, pl.R, pl.fma, pl.guard, LAUNCH_WGT);
 #undef LAUNCH_WGT
-        c->cur ^= 1;
         return;
     }
 #define LAUNCH_TB(T_, C_, G_)                                                                                  \
     hipLaunchKernelGGL((k_sweep_matfree_tb<T_, C_, G_>), dim3(pl.tblocks), dim3(256), 0, c->stream, c->lut,    \
-                       c->code, xin, xout, c->nx, c->mesh_ny, c->ny, c->dom_lo, c->own_lo, c->own_h, pl.tcpi, \
+                       c->code, xin, xout, c->nx, c->mesh_ny, c->ny, c->dom_lo, pl.own_lo, pl.own_h, pl.tcpi, \
                        mask, pl.LY, pl.ntx, pl.tgx, pl.tgy, flip, c->tb_xmajor,                              \
                        (c->lut_allb || c->nx != c->nxt) ? 1 : 0, /* padded: the wall column may not be in the last strip */ \
                        c->lut_nrows, pl.shift, pl.omw, c->tb_stamps)
     TB_DISPATCH(pl.T, pl.fma, pl.guard, LAUNCH_TB);
 #undef LAUNCH_TB
-    c->cur ^= 1;
 }
 
 // n sweeps: as many T-sweep passes as fit, the rest one at a time.

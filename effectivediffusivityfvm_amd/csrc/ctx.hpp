@@ -246,6 +246,9 @@ struct SweepPlan {
     int T_override = 0;                                   // slab mode plans a T = 1 pass for remainders
     bool guard = false;
     int impl = 1, R = 0, NW = 8;                          // 1 = streaming kernel, 2 = workgroup tiles of NW waves x R rows
+    // rows the plan updates: band_h > 0 restricts it to the band [band_lo, band_lo + band_h) of the context's owned rows
+    // (input); own_lo / own_h are what the planner resolved (output, passed to the kernels)
+    int band_lo = 0, band_h = 0, own_lo = 0, own_h = 0;
 };
 
 // api_core.hip
@@ -263,5 +266,6 @@ int default_tb_impl(const deff_ctx *c);
 int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl);
 void enqueue_sweep(deff_ctx *c, const SweepPlan &pl);
 void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl);
+void launch_tb_pass(deff_ctx *c, const SweepPlan &pl);   // the same launch without flipping x[cur]
 void enqueue_sweeps(deff_ctx *c, const SweepPlan &pl, int64_t n);
 int flux_rows(deff_ctx *c);

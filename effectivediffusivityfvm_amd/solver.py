@@ -458,7 +458,7 @@ class SlabRank:
         return self._pair(self._L.deff_slab_rank_window)
 
     def set_tuning(self, key, value):
-        check(self._L.deff_set_tuning(self._ctx, key.encode(), int(value)))
+        check(self._L.deff_slab_rank_set_tuning(self._s, key.encode(), int(value)))
 
     def set_image(self, pix_full):
         a, n = self.window()

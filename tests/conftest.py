@@ -43,3 +43,26 @@ def oracle():
     import oracle_binding as ob
     ob.build()
     return ob
+
+
+def spawn_with_timeout(fn, args, nprocs, timeout_s=300):
+    """torch.multiprocessing.spawn with a deadline: fresh child processes (spawn start method), joined in a loop; when the
+    deadline passes the CHILDREN are killed (exact PIDs) and the test fails -- a wedged rank (a collective that never
+    completes) must not stall the whole suite.  Nothing is re-executed and no process that touched the GPU is replaced."""
+    import time
+    import torch.multiprocessing as mp
+    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    deadline = time.monotonic() + timeout_s
+    try:
+        while not ctx.join(timeout=5):
+            if time.monotonic() > deadline:
+                for p in ctx.processes:
+                    if p.is_alive():
+                        p.kill()
+                for p in ctx.processes:
+                    p.join(10)
+                pytest.fail(f"{fn.__name__}: {nprocs} ranks did not finish within {timeout_s} s (children killed)")
+    finally:
+        for p in ctx.processes:
+            if p.is_alive():
+                p.kill()

@@ -79,7 +79,8 @@ def test_two_rank_batch_equals_single_rank(oracle, tmp_path, num_images):
     single = batch.run_batch(OracleSolver(oracle), _load, num_images, 1e-3, 1.0, 0.0, 1.0, 1e-6, 200)
     assert single.shape == (num_images, 9)
     assert list(single[:, 0]) == list(range(num_images))
-    mp.spawn(_worker, args=(2, _free_port(), num_images, str(tmp_path)), nprocs=2, join=True)
+    from conftest import spawn_with_timeout
+    spawn_with_timeout(_worker, (2, _free_port(), num_images, str(tmp_path)), 2, timeout_s=240)
     table = np.load(tmp_path / "table.npy")
     assert np.array_equal(table, single)
 

@@ -422,9 +422,10 @@ def test_batch_synthetic_first_check_at_1024(pkg, oracle, recorded):
 
 # ----------------------------------------------------------------- row slabs
 
+@pytest.mark.parametrize("overlap", [1, 0])
 @pytest.mark.parametrize("nslabs", [2, 3, 4])
 @pytest.mark.parametrize("T", [0, 2, 8])
-def test_row_slabs_equal_single_domain(pkg, oracle, nslabs, T):
+def test_row_slabs_equal_single_domain(pkg, oracle, nslabs, T, overlap):
     """One image over several slabs with halo exchange once per blocked pass (all slabs on
     device 0 here): the assembled field is bit-identical to the oracle / one-context field, the
     fluxes and Deff too (they are summed in global row order)."""
@@ -438,6 +439,9 @@ def test_row_slabs_equal_single_domain(pkg, oracle, nslabs, T):
     with pkg.SlabGroup(nx, NY, [0] * nslabs) as g:
         first, count = g.layout()
         assert first[0] == 0 and sum(count) == NY and all(c >= 8 for c in count)
+        # overlap 1 (default): per pass the two boundary bands, the exchange on a second stream, the interior meanwhile;
+        # overlap 0: pass, exchange, pass on one stream.  Same bits either way.
+        g.set_tuning("slab_overlap", overlap)
         g.set_tuning("tb_T", T)
         g.set_image(pix)
         g.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
@@ -578,7 +582,8 @@ def test_rccl_slabs_two_ranks(pkg, oracle, tmp_path):
     A, b = oracle.discretize(D, 0.0, 1.0)
     it, deff, conv, x, _, _ = oracle.jacobi(A, b, oracle.linear_guess(nx, NY, 0.0, 1.0), D, 0.0, 1.0, 1e-3, 2000,
                                             check_every=100)
-    mp.spawn(_rccl_slab_worker, args=(2, str(tmp_path / "id"), nx, NY, str(tmp_path)), nprocs=2, join=True)
+    from conftest import spawn_with_timeout
+    spawn_with_timeout(_rccl_slab_worker, (2, str(tmp_path / "id"), nx, NY, str(tmp_path)), 2, timeout_s=240)
     got = np.concatenate([np.load(tmp_path / "x0.npy"), np.load(tmp_path / "x1.npy")])
     assert_field(got, x)
     for k in range(2):
@@ -626,7 +631,8 @@ def test_slab_ranks_three_processes_one_gpu(pkg, oracle, tmp_path):
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    mp.spawn(_gloo_slab_worker, args=(world, port, nx, NY, str(tmp_path)), nprocs=world, join=True)
+    from conftest import spawn_with_timeout
+    spawn_with_timeout(_gloo_slab_worker, (world, port, nx, NY, str(tmp_path)), world, timeout_s=240)
     got = np.concatenate([np.load(tmp_path / f"x{k}.npy") for k in range(world)])
     assert_field(got, x)
     for k in range(world):
@@ -980,7 +986,8 @@ def test_slab_ranks_three_phase_three_processes(pkg, oracle, tmp_path):
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    mp.spawn(_gloo_slab_worker, args=(world, port, nx, NY, str(tmp_path), True), nprocs=world, join=True)
+    from conftest import spawn_with_timeout
+    spawn_with_timeout(_gloo_slab_worker, (world, port, nx, NY, str(tmp_path), True), world, timeout_s=240)
     got = np.concatenate([np.load(tmp_path / f"x{k}.npy") for k in range(world)])
     assert_field(got, x)
     for k in range(world):
