@@ -92,7 +92,7 @@ def bench_slab_one_gpu(args, pkg, torch, local_rank):
         s.init_linear(0.0, 1.0)
         out["one_context"] = run(s)
         launches, T = s.last_launches()
-    for tag, ov in (("slabs_overlap", 1), ("slabs_serial", 0)):
+    for tag, ov in (("slabs_overlap", 2), ("slabs_serial", 0)):
         with pkg.SlabGroup(n, n, [local_rank] * N) as g:
             g.set_tuning("slab_overlap", ov)
             g.synth_image(12345, 0)

@@ -44,13 +44,16 @@ struct SlabPass {
     bool split = false;
 };
 
-static int slab_pass_plans(deff_ctx *c, double omega, int T_override, bool overlap, SlabPass *sp)
+// overlap: 0 = never split, 1 = split when it pays (a slab of >= 16 Mi cells: three launches + the stream hand-overs
+// cost ~10 us of host time per pass, which a small slab does not have -- 4 slabs of 4096 x 1024 on one GPU: 226 us per
+// pass split against 185 us unsplit, whereas 4 slabs of 16384 x 4096 hide the exchange completely), 2 = always
+static int slab_pass_plans(deff_ctx *c, double omega, int T_override, int overlap, SlabPass *sp)
 {
     sp->whole = SweepPlan();
     sp->whole.T_override = T_override;
     TRY(plan_sweeps(c, omega, &sp->whole));
     if (sp->whole.kernel != DEFF_KERNEL_MATFREE_TB) return fail(DEFF_ESTATE, "row-slab mode needs the temporally blocked kernel");
-    sp->split = overlap && c->own_h >= 3 * SLAB_HALO;
+    sp->split = (overlap == 2 || (overlap == 1 && c->n >= ((size_t)1 << 24))) && c->own_h >= 3 * SLAB_HALO;
     if (!sp->split) return DEFF_OK;
     const int lo[3] = {c->own_lo, c->own_lo + c->own_h - SLAB_HALO, c->own_lo + SLAB_HALO};
     const int h[3] = {SLAB_HALO, SLAB_HALO, c->own_h - 2 * SLAB_HALO};
@@ -358,8 +361,8 @@ static int slab_plans(deff_slab_group *g, double omega, std::vector<SlabPass> &p
         deff_ctx *c = g->ctx[r];
         TRY(use_device(c));
         if (c->tb_T > SLAB_HALO) return fail(DEFF_EINVAL, "tb_T exceeds the slab halo depth %d", SLAB_HALO);
-        TRY(slab_pass_plans(c, omega, 0, g->overlap != 0, &plT[r]));
-        TRY(slab_pass_plans(c, omega, 1, g->overlap != 0, &pl1[r]));
+        TRY(slab_pass_plans(c, omega, 0, g->overlap, &plT[r]));
+        TRY(slab_pass_plans(c, omega, 1, g->overlap, &pl1[r]));
         c->last_launches = 0;
         // all slabs of one image advance in lock-step: one T, one exchange per pass
         if (plT[r].whole.T != plT[0].whole.T)
@@ -458,7 +461,7 @@ DEFF_API_CATCH
 extern "C" int deff_slab_group_set_tuning(deff_slab_group *g, const char *key, int value)
 try {
     if (!g) return fail(DEFF_EINVAL, "group is NULL");
-    if (key && !strcmp(key, "slab_overlap")) { g->overlap = value ? 1 : 0; return DEFF_OK; }
+    if (key && !strcmp(key, "slab_overlap")) { g->overlap = value > 2 ? 2 : value; return DEFF_OK; }
     for (int r = 0; r < g->n; ++r) TRY(deff_set_tuning(g->ctx[r], key, value));
     return DEFF_OK;
 }
@@ -627,7 +630,7 @@ DEFF_API_CATCH
 extern "C" int deff_slab_rank_set_tuning(deff_slab_rank *s, const char *key, int value)
 try {
     if (!s || !key) return fail(DEFF_EINVAL, "NULL argument");
-    if (!strcmp(key, "slab_overlap")) { s->overlap = value ? 1 : 0; return DEFF_OK; }
+    if (!strcmp(key, "slab_overlap")) { s->overlap = value > 2 ? 2 : value; return DEFF_OK; }
     return deff_set_tuning(s->ctx, key, value);
 }
 DEFF_API_CATCH
@@ -782,8 +785,8 @@ static int rank_plans(deff_slab_rank *s, double omega, SlabPass *plT, SlabPass *
     deff_ctx *c = s->ctx;
     TRY(use_device(c));
     if (c->tb_T > SLAB_HALO) return fail(DEFF_EINVAL, "tb_T exceeds the slab halo depth %d", SLAB_HALO);
-    TRY(slab_pass_plans(c, omega, 0, s->overlap != 0 && s->nranks > 1, plT));
-    TRY(slab_pass_plans(c, omega, 1, s->overlap != 0 && s->nranks > 1, pl1));
+    TRY(slab_pass_plans(c, omega, 0, s->nranks > 1 ? s->overlap : 0, plT));
+    TRY(slab_pass_plans(c, omega, 1, s->nranks > 1 ? s->overlap : 0, pl1));
     c->last_launches = 0;
     return DEFF_OK;
 }

@@ -210,8 +210,9 @@ int deff_slab_rank_destroy(deff_slab_rank *s);
 int deff_slab_rank_layout(const deff_slab_rank *s, int *first_row, int *row_count);   /* rows it owns */
 int deff_slab_rank_window(const deff_slab_rank *s, int *first_row, int *row_count);   /* rows it holds */
 int deff_slab_rank_context(deff_slab_rank *s, deff_ctx **ctx);   /* for set_tuning / assemble_2phase / init_linear */
-/* deff_set_tuning() of the slab's context, plus "slab_overlap" (1 = default: the halo exchange of a pass runs on a second
- * stream while the interior of the slab is still being swept; 0 = pass, exchange, pass on one stream) */
+/* deff_set_tuning() of the slab's context, plus "slab_overlap": the halo exchange of a pass runs on a second stream while
+ * the interior of the slab is still being swept -- 0 = never (pass, exchange, pass on one stream), 1 = default: for slabs
+ * of 16 Mi cells and more, 2 = always */
 int deff_slab_rank_set_tuning(deff_slab_rank *s, const char *key, int value);
 int deff_slab_rank_set_image_window(deff_slab_rank *s, const uint8_t *pix_window);
 /* 3-phase system of this rank's slab; Grid_window = the rows deff_slab_rank_window() names, or NULL */
