@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "explicit", "scalar", "matfree", "matfree_tb"])
     ap.add_argument("--omega", type=float, default=2.0 / 3.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-small-image", action="store_true", help="skip the ONE-1024^2-image row (profiling runs: its "
+                                                                  "launches would mix into the per-kernel averages)")
     ap.add_argument("--explicit-sweeps", type=int, default=300,
                     help="sweeps of the secondary explicit-coefficient measurement (0 = skip)")
     ap.add_argument("--tune", action="append", default=[], help="key=value tuning knob (repeatable)")
@@ -277,7 +279,7 @@ def main():
     # fourth reported row: BASELINE config #2's shape -- ONE 1024^2 image (too few cells to fill the chip with one wave
     # per tile: the planner switches to workgroup tiles, kernels_wgtile.hpp); same physics, its own small context
     small = None
-    if rank == 0 and n != 1024 and args.batch == 1:
+    if rank == 0 and n != 1024 and args.batch == 1 and not args.no_small_image:
         with pkg.Solver(1024, 1024, device=local_rank, kernel=args.kernel) as s2:
             s2.synth_image(12345, 0)
             s2.assemble_2phase(1e-3, 1.0, 0.0, 1.0)

@@ -122,6 +122,8 @@ try {
                     c->Dl, c->Dr, c->mf, c->x[0], c->x[1], c->scratch, c->active};
     for (void *p : bufs) if (p) (void)hipFree(p);
     if (c->mf_host) (void)hipHostFree(c->mf_host);
+    if (c->q) (void)hipFree(c->q);
+    if (c->q_host) (void)hipHostFree(c->q_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -210,6 +212,7 @@ try {
     else if (!strcmp(key, "tb_LY")) c->tb_LY = value;
     else if (!strcmp(key, "tb_impl")) c->tb_impl = value > 2 ? 0 : value;
     else if (!strcmp(key, "tb_R")) c->tb_R = value;
+    else if (!strcmp(key, "flux_reduce")) c->flux_reduce = value > 2 ? 0 : value;
     else if (!strcmp(key, "tb_NW")) c->tb_NW = value;
     else if (!strcmp(key, "dict")) c->dict_enabled = value ? 1 : 0;
     else if (!strcmp(key, "tb_xmajor")) c->tb_xmajor = value ? 1 : 0;

@@ -451,26 +451,48 @@ DEFF_API_CATCH
 
 // Wall fluxes of the current field (cuh:1256-1257) for every stacked row, brought to the
 // pinned host buffer: mf_host[0..rows) left wall, mf_host[rows..2*rows) right wall.
-int flux_rows(deff_ctx *c)
+int flux_rows(deff_ctx *c, bool need_rows)
 {
     if (!c->have_walls)
         return fail(DEFF_ESTATE, "wall diffusivities unknown: pass D to deff_set_system() or assemble on the device");
     hipLaunchKernelGGL(k_wall_flux, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, c->x[c->cur], c->Dl,
                        c->Dr, c->nx, c->nxt, c->rows, c->dx, c->CL, c->CR, c->mf);
     HIP_TRY(hipGetLastError());
+    c->q_valid = false;
+    if (c->flux_reduce && !c->slab) {
+        // sums on the device (kernels_setup.hpp: k_flux_sum): the check moves 16 B per image
+        TRY(dev_alloc(&c->q, (size_t)2 * c->nimg));
+        if (!c->q_host) HIP_TRY(hipHostMalloc((void **)&c->q_host, sizeof(double) * 2 * c->nimg));
+        const dim3 grid((c->nimg + 3) / 4);
+        if (c->flux_reduce == 2) hipLaunchKernelGGL(k_flux_sum<true>, grid, dim3(256), 0, c->stream, c->mf, c->rows, c->ny, c->nimg, c->q);
+        else hipLaunchKernelGGL(k_flux_sum<false>, grid, dim3(256), 0, c->stream, c->mf, c->rows, c->ny, c->nimg, c->q);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(c->q_host, c->q, sizeof(double) * 2 * c->nimg, hipMemcpyDeviceToHost, c->stream));
+        c->q_valid = true;
+        if (!need_rows) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            return DEFF_OK;
+        }
+    }
     HIP_TRY(hipMemcpyAsync(c->mf_host, c->mf, sizeof(double) * 2 * c->rows, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DEFF_OK;
 }
 
-// Deff of image k from its rows of mf_host, summed in row order like the reference (cuh:1258-1263).
+// Deff of image k from its wall fluxes, summed in row order like the reference (cuh:1258-1263): on the host from
+// mf_host, or from the device's sums when flux_rows() produced them.
 static double deff_of_image(const deff_ctx *c, int k)
 {
-    const double *L = c->mf_host + (size_t)k * c->ny, *R = c->mf_host + c->rows + (size_t)k * c->ny;
     double Q1 = 0, Q2 = 0;
-    for (int j = 0; j < c->ny; ++j) {
-        Q1 += L[j];
-        Q2 += R[j];
+    if (c->q_valid) {
+        Q1 = c->q_host[2 * k];
+        Q2 = c->q_host[2 * k + 1];
+    } else {
+        const double *L = c->mf_host + (size_t)k * c->ny, *R = c->mf_host + c->rows + (size_t)k * c->ny;
+        for (int j = 0; j < c->ny; ++j) {
+            Q1 += L[j];
+            Q2 += R[j];
+        }
     }
     const double qAvg = (Q1 + Q2) / (2.0 * c->ny);
     return qAvg / ((c->CR - c->CL));
@@ -489,7 +511,7 @@ try {
     if (!c->have_field) return fail(DEFF_ESTATE, "no field");
     TRY(use_device(c));
     TRY(consolidate(c));
-    TRY(flux_rows(c));
+    TRY(flux_rows(c, MFL || MFR));
     for (int k = 0; k < c->nimg; ++k) deff_raw[k] = deff_of_image(c, k);
     copy_fluxes(c, MFL, MFR);
     return DEFF_OK;
@@ -532,7 +554,7 @@ try {
         for (int k = 0; k < B; ++k)
             if (c->active_h[k]) { iters[k] = iter; c->buf_of[k] = (uint8_t)c->cur; }
         if (do_check) {
-            TRY(flux_rows(c));
+            TRY(flux_rows(c, MFL || MFR));
             bool froze = false;
             for (int k = 0; k < B; ++k) {
                 if (!c->active_h[k]) continue;
@@ -709,7 +731,7 @@ try {
         TRY(stream_push_mask(c, n_active));
         // one sweep (the first of the newly loaded images, sweep j*C + 1 of the others), then the check
         TRY(advance(pl, 1));
-        TRY(flux_rows(c));
+        TRY(flux_rows(c, false));                      // a stream reports no per-row fluxes
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
         HIP_TRY(hipEventSynchronize(c->ev1));
         float ms = 0;

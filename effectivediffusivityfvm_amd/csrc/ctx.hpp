@@ -108,6 +108,13 @@ struct deff_ctx {
     bool have_walls = false;
     double *mf = nullptr;           // device: 2*ny fluxes
     double *mf_host = nullptr;      // pinned
+    // where the fluxes are summed: 0 = on the host, in row order (default); 1 = on the device in the same order (bit-identical;
+    // a check then moves 16 B per image instead of 16 B per row); 2 = on the device by a wave-level tree (fixed order, not the
+    // reference's: ~1e-16 relative).  Row slabs always sum on the host (the rows of one image live on several devices).
+    int flux_reduce = 0;
+    double *q = nullptr;            // device: {Q1, Q2} per image
+    double *q_host = nullptr;       // pinned
+    bool q_valid = false;           // q_host holds the sums of the last flux_rows()
 
     // field, ping-pong
     double *x[2] = {nullptr, nullptr};
@@ -268,4 +275,4 @@ void enqueue_sweep(deff_ctx *c, const SweepPlan &pl);
 void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl);
 void launch_tb_pass(deff_ctx *c, const SweepPlan &pl);   // the same launch without flipping x[cur]
 void enqueue_sweeps(deff_ctx *c, const SweepPlan &pl, int64_t n);
-int flux_rows(deff_ctx *c);
+int flux_rows(deff_ctx *c, bool need_rows = true);

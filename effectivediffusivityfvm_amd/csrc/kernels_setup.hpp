@@ -257,4 +257,29 @@ static __global__ void k_wall_flux(const double *__restrict__ x, const double *_
     mf[rows + i] = Dr[i] * (CR - x[(size_t)i * nx + nxt - 1]) / (dx / 2.0);
 }
 
+// Device-side sums of the wall fluxes (cuh:1258-1259), one WAVE per image, q[img] = {Q1, Q2}.
+//   TREE = false: lane 0 adds the image's ny values in row order -- the reference's order, bit-identical to the host sum;
+//   TREE = true : lane l adds rows l, l+64, ..., then a fixed butterfly over the 64 partial sums (wavefront-level
+//                 reduction): deterministic, ~1e-16 relative from the serial order, ny/64 dependent adds instead of ny.
+template <bool TREE>
+static __global__ void k_flux_sum(const double *__restrict__ mf, int rows, int ny, int nimg, double *__restrict__ q)
+{
+    const int img = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (img >= nimg) return;
+    const double *L = mf + (size_t)img * ny, *R = mf + rows + (size_t)img * ny;
+    double q1 = 0, q2 = 0;
+    if constexpr (TREE) {
+        for (int j = lane; j < ny; j += 64) { q1 += L[j]; q2 += R[j]; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            q1 += __shfl_xor(q1, off, 64);
+            q2 += __shfl_xor(q2, off, 64);
+        }
+    } else {
+        if (lane != 0) return;
+        for (int j = 0; j < ny; ++j) { q1 += L[j]; q2 += R[j]; }
+    }
+    if (lane == 0) { q[2 * img] = q1; q[2 * img + 1] = q2; }
+}
+
 }  // namespace deff

@@ -91,6 +91,56 @@ __device__ __forceinline__ double tb_cell(const double *lut, unsigned off, doubl
     }
 }
 
+// The two cells of a lane TOGETHER, one arithmetic stage at a time: cell by cell (two tb_cell() calls) hipcc emits each
+// cell's seven-deep dependent chain back to back, so that a wave has a single chain in flight; written stage-wise the two
+// chains interleave and every FP64 instruction has another between itself and its consumer.  Same operations, same order
+// per cell, same bits.  (TB_PAIR = 0 restores the cell-by-cell form for A/B runs.)
+#ifndef TB_PAIR
+#define TB_PAIR 1
+#endif
+#ifndef TB_FENCE_EVERY
+#define TB_FENCE_EVERY 1
+#endif
+template <bool GUARD, bool WALL, bool FMA>
+__device__ __forceinline__ double2 tb_pair(const double *lut, unsigned o0, unsigned o1, double2 vC, double xw0, double xe1,
+                                           double2 vS, double2 vN, double omw)
+{
+    if constexpr (GUARD || !TB_PAIR) {
+        double2 o;
+        o.x = tb_cell<GUARD, WALL, FMA>(lut, o0, vC.x, xw0, vC.y, vS.x, vN.x, omw);
+        o.y = tb_cell<GUARD, WALL, FMA>(lut, o1, vC.y, vC.x, xe1, vS.y, vN.y, omw);
+        return o;
+    } else {
+        constexpr int PS = LUT_PLANE_STRIDE * 8;
+        const char *b0 = reinterpret_cast<const char *>(lut) + o0, *b1 = reinterpret_cast<const char *>(lut) + o1;
+        const double aW0 = *reinterpret_cast<const double *>(b0 + PS), aW1 = *reinterpret_cast<const double *>(b1 + PS);
+        const double aE0 = *reinterpret_cast<const double *>(b0 + 2 * PS), aE1 = *reinterpret_cast<const double *>(b1 + 2 * PS);
+        const double aS0 = *reinterpret_cast<const double *>(b0 + 3 * PS), aS1 = *reinterpret_cast<const double *>(b1 + 3 * PS);
+        const double aN0 = *reinterpret_cast<const double *>(b0 + 4 * PS), aN1 = *reinterpret_cast<const double *>(b1 + 4 * PS);
+        const double c00 = *reinterpret_cast<const double *>(b0), c01 = *reinterpret_cast<const double *>(b1);
+        double bb0 = 0.0, bb1 = 0.0;
+        if constexpr (WALL) {
+            bb0 = *reinterpret_cast<const double *>(b0 + 5 * PS);
+            bb1 = *reinterpret_cast<const double *>(b1 + 5 * PS);
+        }
+        double s0 = aW0 * xw0, s1 = aW1 * vC.x;
+        s0 = mul_add<FMA>(aE0, vC.y, s0); s1 = mul_add<FMA>(aE1, xe1, s1);
+        s0 = mul_add<FMA>(aS0, vS.x, s0); s1 = mul_add<FMA>(aS1, vS.y, s1);
+        s0 = mul_add<FMA>(aN0, vN.x, s0); s1 = mul_add<FMA>(aN1, vN.y, s1);
+        s0 = bb0 - s0; s1 = bb1 - s1;
+        double2 o;
+        if constexpr (FMA) {
+            s0 = c00 * s0; s1 = c01 * s1;
+            o.x = __builtin_fma(omw, vC.x, s0); o.y = __builtin_fma(omw, vC.y, s1);
+        } else {
+            const double m0 = omw * vC.x, m1 = omw * vC.y;
+            s0 = c00 * s0; s1 = c01 * s1;
+            o.x = m0 + s0; o.y = m1 + s1;
+        }
+        return o;
+    }
+}
+
 // One strip x chunk: the whole row pipeline of a wave (2 cells per lane, 128 columns).
 // Geometry (array rows): the mesh of this image is rows [row_lo, row_lo+ny) -- rows outside it
 // are "outside the mesh" even if another image of a batch lives there, and row_lo is negative
@@ -227,9 +277,7 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
                 const double xw0 = from_lane_below(vC.y);
                 const double xe1 = from_lane_above(vC.x);
                 const unsigned o0 = cw[t] & 0xFFFFu, o1 = cw[t] >> 16;
-                double2 o;
-                o.x = tb_cell<GUARD, WALL, FMA>(lut, o0, vC.x, xw0, vC.y, vS.x, vN.x, omw);
-                o.y = tb_cell<GUARD, WALL, FMA>(lut, o1, vC.y, vC.x, xe1, vS.y, vN.y, omw);
+                const double2 o = tb_pair<GUARD, WALL, FMA>(lut, o0, o1, vC, xw0, xe1, vS, vN, omw);
                 if (t == T && ph == TB_TOUCH_PH) {
                     // CDNA counts loads and stores in one vmcnt and lets stores complete out of order, so
                     // "the prefetched rows have arrived" can only be expressed as vmcnt(0), which also
@@ -248,7 +296,7 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
                 // keep the scheduler from pulling the next sweeps' table lookups up here: left
                 // alone it hoists them all (180-250 VGPRs, 1-2 waves per SIMD); with the fence a
                 // step keeps ~120 VGPRs and 4 waves per SIMD hide the LDS latency instead
-                __builtin_amdgcn_sched_barrier(0);
+                if ((t % TB_FENCE_EVERY) == 0 || t == T) __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -268,7 +316,7 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
 // Row slab (one image): dom_lo = -(first array row's global index), ny = global height,
 // own_lo = halo depth, own_h = rows owned by this rank.
 template <int T, bool FMA, bool GUARD>
-__global__ __launch_bounds__(256) void k_sweep_matfree_tb(const double *__restrict__ lut_g,
+__global__ __launch_bounds__(256, (T >= 8 ? 3 : 1)) void k_sweep_matfree_tb(const double *__restrict__ lut_g,
                                                           const uint16_t *__restrict__ code,
                                                           const double *__restrict__ x,
                                                           double *__restrict__ xnew, int nx, int ny,

@@ -143,14 +143,15 @@ class Solver:
         return x
 
     # -- solve ------------------------------------------------------------
-    def solve(self, tol, max_iter, omega=OMEGA_REFERENCE, check_every=10000):
+    def solve(self, tol, max_iter, omega=OMEGA_REFERENCE, check_every=10000, fluxes=True):
         """One image: a SolveResult.  Batch: a list with one SolveResult per image (MFL/MFR
-        are that image's rows)."""
+        are that image's rows; fluxes=False passes NULL for them, as a caller that only wants Deff does)."""
         res = (Result * self.nimg)()
         MFL = np.zeros(self.rows)
         MFR = np.zeros(self.rows)
         check(self._L.deff_solve_batch(self._ctx, omega, tol, int(max_iter), int(check_every), res,
-                                       MFL.ctypes.data_as(C.c_void_p), MFR.ctypes.data_as(C.c_void_p)))
+                                       MFL.ctypes.data_as(C.c_void_p) if fluxes else None,
+                                       MFR.ctypes.data_as(C.c_void_p) if fluxes else None))
         outs = []
         for k in range(self.nimg):
             out = SolveResult()

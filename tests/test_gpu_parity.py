@@ -1392,3 +1392,40 @@ def test_stream_callback_errors_surface(pkg, monkeypatch):
         monkeypatch.setattr(solver_mod, "SolveResult", broken)
         with pytest.raises(Boom):
             s.solve_stream(iter(imgs), 1e-2, 1.0, 0.0, 1.0, 1e-3, 200, check_every=50)
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_device_side_flux_sums(pkg, oracle, B):
+    """flux_reduce = 1: the wall fluxes are added up on the device IN ROW ORDER (the reference's order, cuh:1258-1259), one
+    wave per image, so a check moves 16 bytes per image instead of 16 per row: iteration counts, Deff and conv must be the
+    bits of the host-summed run and of the oracle.  flux_reduce = 2: a wave-level tree (fixed order, not the reference's):
+    Deff within 1e-13, inside the north-star's 1e-8, and the same stopping decisions on this case."""
+    nx, ny = 130, 70
+    rng = np.random.default_rng(17 + B)
+    pixs = [rand_mask(rng, nx, ny, 0.4 + 0.1 * k) for k in range(B)]
+    want = []
+    for k in range(B):
+        D = oracle.fill_D_2phase(pixs[k], 1.0, 1e-2)
+        A, b = oracle.discretize(D, 0.0, 1.0)
+        want.append(oracle.jacobi(A, b, oracle.linear_guess(nx, ny, 0.0, 1.0), D, 0.0, 1.0, 1e-4, 6000, check_every=200))
+    for mode in (0, 1, 2):
+        for fluxes in (True, False):
+            with pkg.Solver(nx, ny, nimg=B) as s:
+                s.set_tuning("flux_reduce", mode)
+                s.set_image(np.stack(pixs) if B > 1 else pixs[0])
+                s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+                s.init_linear(0.0, 1.0)
+                res = s.solve(1e-4, 6000, check_every=200, fluxes=fluxes)
+                got = s.get_field()
+                d_after, _, _ = s.flux()
+            res = res if isinstance(res, list) else [res]
+            for k in range(B):
+                it, deff, conv, x, MFL, MFR = want[k]
+                assert res[k].iters == it
+                if mode < 2:
+                    assert (res[k].deff_raw, res[k].conv) == (deff, conv)
+                else:
+                    assert abs(res[k].deff_raw - deff) <= 1e-13 * abs(deff)
+                if fluxes:
+                    assert np.array_equal(res[k].MFL, MFL) and np.array_equal(res[k].MFR, MFR)
+                assert_field(got[k * ny:(k + 1) * ny], x)
