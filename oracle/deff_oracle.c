@@ -18,12 +18,19 @@
  *
  * Parity pinning: the reference cannot be built in this image (it needs
  * cuda_runtime.h / nvcc launch syntax; no stand-ins are written).  The oracle
- * is pinned against (i) the analytic known-answer cases of the reference's
- * own documentation (doc section 5.3) and (ii) the reference outputs recorded
- * by the survey stage in SURVEY.md section 6 / 8c and BASELINE.md section 2
- * (110 001 sweeps, Deff 0.18286248993335813 on 00000.jpg; first-check Deff on
- * the synthetic masks; sweep counts of the analytic table).  See
- * tests/test_oracle_golden.py.
+ * is pinned against what /root/reference itself holds:
+ *   (i)   the reference's own stb_image.h, compiled as it lies by
+ *         tests/golden/make_stb_fixture.py: the decoded bytes of 00000.jpg are
+ *         the pixel fixture every config-#1 golden here is derived from;
+ *   (ii)  the worked cases of the reference's documentation (doc 5.3.1-5.3.3):
+ *         thin phase -> 33.33, three phases in parallel -> 371250.4, wide
+ *         domain W = 2H -> equation (8)  (tests/test_doc_kats.py);
+ *   (iii) the doc's analytic stripe cases, equations (7) and (8).
+ * The numbers the survey stage recorded from a CUDA-header-stand-in build
+ * (110 001 sweeps and Deff 0.18286248993335813 /
+ * ...824 on 00000.jpg, first-check Deff on the synthetic masks) are reproduced
+ * too, as cross-checks; they pin nothing by themselves.
+ * See tests/test_oracle_golden.py, tests/test_doc_kats.py, DESIGN.md section 2.
  */
 #include <math.h>
 #include <stdint.h>
