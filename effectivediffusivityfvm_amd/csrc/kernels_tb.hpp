@@ -98,9 +98,45 @@ __device__ __forceinline__ double tb_cell(const double *lut, unsigned off, doubl
 #ifndef TB_PAIR
 #define TB_PAIR 1
 #endif
-#ifndef TB_FENCE_EVERY
-#define TB_FENCE_EVERY 1
-#endif
+// the matrix rows of a lane's two cells
+struct TbCoef {
+    double c0[2], aW[2], aE[2], aS[2], aN[2], b[2];
+};
+template <bool WALL>
+__device__ __forceinline__ void tb_lookup(const double *lut, unsigned codes, TbCoef &k)
+{
+    constexpr int PS = LUT_PLANE_STRIDE * 8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const char *base = reinterpret_cast<const char *>(lut) + (h ? (codes >> 16) : (codes & 0xFFFFu));
+        k.aW[h] = *reinterpret_cast<const double *>(base + PS);
+        k.aE[h] = *reinterpret_cast<const double *>(base + 2 * PS);
+        k.aS[h] = *reinterpret_cast<const double *>(base + 3 * PS);
+        k.aN[h] = *reinterpret_cast<const double *>(base + 4 * PS);
+        k.c0[h] = *reinterpret_cast<const double *>(base);
+        if constexpr (WALL) k.b[h] = *reinterpret_cast<const double *>(base + 5 * PS);
+        else k.b[h] = 0.0;
+    }
+}
+template <bool FMA>
+__device__ __forceinline__ double2 tb_apply(const TbCoef &k, double2 vC, double xw0, double xe1, double2 vS, double2 vN, double omw)
+{
+    double s0 = k.aW[0] * xw0, s1 = k.aW[1] * vC.x;
+    s0 = mul_add<FMA>(k.aE[0], vC.y, s0); s1 = mul_add<FMA>(k.aE[1], xe1, s1);
+    s0 = mul_add<FMA>(k.aS[0], vS.x, s0); s1 = mul_add<FMA>(k.aS[1], vS.y, s1);
+    s0 = mul_add<FMA>(k.aN[0], vN.x, s0); s1 = mul_add<FMA>(k.aN[1], vN.y, s1);
+    s0 = k.b[0] - s0; s1 = k.b[1] - s1;
+    double2 o;
+    if constexpr (FMA) {
+        s0 = k.c0[0] * s0; s1 = k.c0[1] * s1;
+        o.x = __builtin_fma(omw, vC.x, s0); o.y = __builtin_fma(omw, vC.y, s1);
+    } else {
+        const double m0 = omw * vC.x, m1 = omw * vC.y;
+        s0 = k.c0[0] * s0; s1 = k.c0[1] * s1;
+        o.x = m0 + s0; o.y = m1 + s1;
+    }
+    return o;
+}
 template <bool GUARD, bool WALL, bool FMA>
 __device__ __forceinline__ double2 tb_pair(const double *lut, unsigned o0, unsigned o1, double2 vC, double xw0, double xe1,
                                            double2 vS, double2 vN, double omw)
@@ -111,33 +147,9 @@ __device__ __forceinline__ double2 tb_pair(const double *lut, unsigned o0, unsig
         o.y = tb_cell<GUARD, WALL, FMA>(lut, o1, vC.y, vC.x, xe1, vS.y, vN.y, omw);
         return o;
     } else {
-        constexpr int PS = LUT_PLANE_STRIDE * 8;
-        const char *b0 = reinterpret_cast<const char *>(lut) + o0, *b1 = reinterpret_cast<const char *>(lut) + o1;
-        const double aW0 = *reinterpret_cast<const double *>(b0 + PS), aW1 = *reinterpret_cast<const double *>(b1 + PS);
-        const double aE0 = *reinterpret_cast<const double *>(b0 + 2 * PS), aE1 = *reinterpret_cast<const double *>(b1 + 2 * PS);
-        const double aS0 = *reinterpret_cast<const double *>(b0 + 3 * PS), aS1 = *reinterpret_cast<const double *>(b1 + 3 * PS);
-        const double aN0 = *reinterpret_cast<const double *>(b0 + 4 * PS), aN1 = *reinterpret_cast<const double *>(b1 + 4 * PS);
-        const double c00 = *reinterpret_cast<const double *>(b0), c01 = *reinterpret_cast<const double *>(b1);
-        double bb0 = 0.0, bb1 = 0.0;
-        if constexpr (WALL) {
-            bb0 = *reinterpret_cast<const double *>(b0 + 5 * PS);
-            bb1 = *reinterpret_cast<const double *>(b1 + 5 * PS);
-        }
-        double s0 = aW0 * xw0, s1 = aW1 * vC.x;
-        s0 = mul_add<FMA>(aE0, vC.y, s0); s1 = mul_add<FMA>(aE1, xe1, s1);
-        s0 = mul_add<FMA>(aS0, vS.x, s0); s1 = mul_add<FMA>(aS1, vS.y, s1);
-        s0 = mul_add<FMA>(aN0, vN.x, s0); s1 = mul_add<FMA>(aN1, vN.y, s1);
-        s0 = bb0 - s0; s1 = bb1 - s1;
-        double2 o;
-        if constexpr (FMA) {
-            s0 = c00 * s0; s1 = c01 * s1;
-            o.x = __builtin_fma(omw, vC.x, s0); o.y = __builtin_fma(omw, vC.y, s1);
-        } else {
-            const double m0 = omw * vC.x, m1 = omw * vC.y;
-            s0 = c00 * s0; s1 = c01 * s1;
-            o.x = m0 + s0; o.y = m1 + s1;
-        }
-        return o;
+        TbCoef k;
+        tb_lookup<WALL>(lut, o0 | (o1 << 16), k);
+        return tb_apply<FMA>(k, vC, xw0, xe1, vS, vN, omw);
     }
 }
 
@@ -171,7 +183,15 @@ __device__ __forceinline__ double2 tb_pair(const double *lut, unsigned o0, unsig
 // sit on four different SIMDs and the mailbox read at the head of every level's dependency chain
 // cost far more than the 11 % of work saved.  Independence of the waves is worth its redundancy.  The
 // code is deliberately written with double2 values and named slots: an array-of-scalars
-// formulation of the same dataflow made hipcc hoist the lookups to 204 VGPRs.)
+// formulation of the same dataflow made hipcc hoist the lookups to 204 VGPRs.
+// Round 2, all A/B in one process at 4096^2 with the two cells stage-wise (tb_pair): lookups one level ahead again, now
+// that __launch_bounds__ holds 3 waves per SIMD -- T = 6 168 VGPRs + 36 B scratch 1 104 against 1 127 G, T = 8 180 B of
+// scratch 700 G, T = 4 152 VGPRs (3 waves instead of 4) 999 against 1 003; b - sigma folded into the next multiply as a
+// negated source where b is identically 0 (20 instead of 22 FP64 instructions; differs from the reference only in the
+// sign of an exact zero when the caller's field holds -0.0) -- T = 8 +-0, T = 6 +2 %: not taken; non-temporal stores of
+// the result row -- +-0; T = 6 forced to 128 VGPRs for 4 waves per SIMD -- 96 B of scratch, 1 003 against 1 160 G;
+// a fence after every 2nd / 4th level instead of every level -- +-0.  Fewer FP64 instructions and earlier lookups change
+// nothing: the kernel is bound by how many waves are READY, not by what they execute.)
 template <int T, bool GUARD, bool WALL, bool FMA>
 __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__restrict__ code,
                                          const double *__restrict__ x, double *__restrict__ xnew, int nx,
@@ -296,7 +316,7 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
                 // keep the scheduler from pulling the next sweeps' table lookups up here: left
                 // alone it hoists them all (180-250 VGPRs, 1-2 waves per SIMD); with the fence a
                 // step keeps ~120 VGPRs and 4 waves per SIMD hide the LDS latency instead
-                if ((t % TB_FENCE_EVERY) == 0 || t == T) __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -316,7 +336,7 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
 // Row slab (one image): dom_lo = -(first array row's global index), ny = global height,
 // own_lo = halo depth, own_h = rows owned by this rank.
 template <int T, bool FMA, bool GUARD>
-__global__ __launch_bounds__(256, (T >= 8 ? 3 : 1)) void k_sweep_matfree_tb(const double *__restrict__ lut_g,
+__global__ __launch_bounds__(256, (T >= 6 ? 3 : 1)) void k_sweep_matfree_tb(const double *__restrict__ lut_g,
                                                           const uint16_t *__restrict__ code,
                                                           const double *__restrict__ x,
                                                           double *__restrict__ xnew, int nx, int ny,
