@@ -370,7 +370,6 @@ def main():
                 "kernel": kernel_used,
                 "sweeps_per_step": S,
                 "sweeps_per_launch": sweeps_per_launch,
-                "deff_raw_after_run": deff,
             },
             "roofline": roofline,
             "per_rank_ms_per_step": per_rank_ms,
