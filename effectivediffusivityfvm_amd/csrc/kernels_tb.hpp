@@ -191,7 +191,16 @@ __device__ __forceinline__ double2 tb_pair(const double *lut, unsigned o0, unsig
 // sign of an exact zero when the caller's field holds -0.0) -- T = 8 +-0, T = 6 +2 %: not taken; non-temporal stores of
 // the result row -- +-0; T = 6 forced to 128 VGPRs for 4 waves per SIMD -- 96 B of scratch, 1 003 against 1 160 G;
 // a fence after every 2nd / 4th level instead of every level -- +-0.  Fewer FP64 instructions and earlier lookups change
-// nothing: the kernel is bound by how many waves are READY, not by what they execute.)
+// nothing: the kernel is bound by how many waves are READY, not by what they execute.
+// The row prefetch without the compiler's waits (hipcc waits vmcnt(0) for the youngest prefetched row, i.e. also for the
+// ACK of the store issued one step earlier; gfx950 retires vector-memory operations in issue order, so vmcnt(3) behind
+// three stores is enough): (a) asm loads into registers + a hand-counted wait -- hipcc copied / reused the destination
+// registers before the wait (an asm load's destination counts as written at the end of the statement): wrong values and,
+// once a reused register held an address, a memory fault; AGPR destinations halve the VGPR budget; (b) LDS-DMA
+// (global_load_lds into a 3 840-B staging area per wave, rows read back by ds_read after `s_waitcnt vmcnt(3)`): correct
+// (every parity test bit-exact: the in-order retirement holds), 158 VGPRs, and NO faster -- 1 204 against 1 233 G at T = 8,
+// 979 against 1 084 at T = 4; with the wait removed altogether (wrong results, timing only) 1 300 G: +8 % is ALL that
+// waiting for global memory costs this kernel.  Not kept.)
 template <int T, bool GUARD, bool WALL, bool FMA>
 __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__restrict__ code,
                                          const double *__restrict__ x, double *__restrict__ xnew, int nx,
