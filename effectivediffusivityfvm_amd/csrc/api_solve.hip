@@ -100,14 +100,17 @@ static void tile_grid(const deff_ctx *c, int cols_per_block, int rows, SweepPlan
 }
 
 // Which form of the temporally blocked pass a context gets when the caller does not say (tb_impl = 0): workgroup tiles
-// (kernels_wgtile.hpp) for ONE image below 4 Mi cells, where the streaming kernel has too few tiles to fill the chip and
-// a tile's dependency chain sets the time of a pass (measured, G cells*iter/s, streaming / workgroup tiles: 512^2 106 / 231,
-// 1024^2 316 / 556, 1536^2 455 / 613, 2048^2 682 / 678, 4096^2 1 128 / 742); stacks and everything larger stream.
+// (kernels_wgtile.hpp) below 4 Mi cells in the context -- one image or a stack --, where the streaming kernel has too few
+// tiles to fill the chip and a tile's dependency chain sets the time of a pass; everything larger streams.  Measured,
+// G cells*iter/s, streaming / workgroup tiles: one image 512^2 106 / 231, 1024^2 316 / 556, 1536^2 455 / 613, 2048^2
+// 682 / 678, 4096^2 1 128 / 742; stacks 16 x 128^2 117 / 239, 64 x 128^2 364 / 683, 200 x 128^2 589 / 652, 16 x 256^2
+// 322 / 418, 48 x 256^2 535 / 535, 12 x 512^2 509 / 618, 2 x 1024^2 426 / 569, 3 x 1024^2 577 / 623 (and 1 024 x 128^2,
+// 16 Mi cells, whole images per wave with no halo: 1 222 streaming).
 // Keyed on tb_ref_cells for slabs, so that every slab of an image takes the same decision (and the same T).
 int default_tb_impl(const deff_ctx *c)
 {
     const size_t cells = c->tb_ref_cells ? c->tb_ref_cells : c->n;
-    return (c->nimg == 1 && cells < ((size_t)1 << 22)) ? 2 : 1;
+    return cells < ((size_t)1 << 22) ? 2 : 1;
 }
 
 int default_tb_T(const deff_ctx *c)

@@ -109,7 +109,14 @@ def test_launch_plan_is_reported(pkg):
         s.sweeps(12)
         p = s.plan()
         assert p["tb_T"] in (4, 6, 8) and p["tb_strips"] == 1 and p["tb_LY"] * p["tb_chunks_per_image"] >= 128
-        assert p["tb_LY"] >= p["tb_T"] and p["tb_blocks"] % 8 == 0 and p["tb_impl"] == 1     # stacks stream
+        assert p["tb_blocks"] % 8 == 0 and p["tb_impl"] == 2          # a stack of 1 Mi cells: workgroup tiles
+    with pkg.Solver(128, 128, nimg=512) as s:
+        s.synth_image(1, 0)
+        s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(16)
+        p = s.plan()
+        assert p["tb_impl"] == 1 and p["tb_strips"] == 1 and p["tb_LY"] * p["tb_chunks_per_image"] >= 128   # 8 Mi cells: streaming
     with pkg.Solver(1024, 1024) as s:
         s.synth_image(1, 0)
         s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
