@@ -45,6 +45,45 @@ FP64_INSTR_PEAK_T = 39.3216
 FP64_INSTR_PER_CELL = {False: 11, True: 7}   # tb_cell(): default arithmetic / contracted (kernels_tb.hpp)
 
 
+def live_traffic(n, kernel, kernel_used):
+    """HBM bytes per launch of the dominant sweep kernel, measured NOW: two child runs of this script under
+    `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE; separate passes, the program itself after `--`), corrected as
+    MI355X_MICROARCH.md prescribes for gfx950 (both counters in KiB; FETCH_SIZE tallies 128-B requests at 64 B: x2).
+    Returns (bytes_per_launch, source) or None (no rocprofv3 / a failed child: the caller falls back to profiles/)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    want = {"matfree_tb": "k_sweep_matfree_tb", "matfree": "k_sweep_matfree<", "explicit": "k_sweep_explicit",
+            "scalar": "k_sweep_scalar"}.get(kernel_used)
+    if want is None:
+        return None
+    got = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.abspath(__file__),
+                   "--size", str(n), "--kernel", kernel, "--steps", "1", "--warmup", "0", "--sweeps-per-step", "24",
+                   "--primary-only"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+                files = glob.glob(os.path.join(tmp, "*", "*_counter_collection.csv"))
+                if r.returncode != 0 or not files:
+                    return None
+                vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(max(files, key=os.path.getmtime)))
+                        if want in row["Kernel_Name"]]
+                if not vals:
+                    return None
+                got[ctr] = sum(vals) / len(vals) * 1024.0
+            except Exception:
+                return None
+    return got["FETCH_SIZE"] * 2.0 + got["WRITE_SIZE"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child runs of this command (x2 read correction, gfx950)"
+
+
 def cpu_baseline(n, seconds_target=12.0):
     """Single-thread oracle sweep rate on the same synthetic workload (bounded sample).
     Returns (block, sweeps, field): the field after `sweeps` sweeps from the linear guess is kept so that
@@ -172,6 +211,10 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "explicit", "scalar", "matfree", "matfree_tb"])
     ap.add_argument("--omega", type=float, default=2.0 / 3.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--primary-only", action="store_true", help="only the timed steps of the primary kernel: no explicit / "
+                                                                "omega-1 / contracted / small-image / CPU legs (counter runs)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="take roofline.traffic from profiles/traffic.json instead of "
+                                                                   "measuring it now (two rocprofv3 --pmc child runs)")
     ap.add_argument("--no-small-image", action="store_true", help="skip the ONE-1024^2-image row (profiling runs: its "
                                                                   "launches would mix into the per-kernel averages)")
     ap.add_argument("--explicit-sweeps", type=int, default=300,
@@ -184,6 +227,9 @@ def main():
     ap.add_argument("--slabs", type=int, default=1, help="--mode slab on ONE GPU: split the image into this many slabs "
                                                          "(one process, peer copies) and report the exchange's exposed time")
     args = ap.parse_args()
+    if args.primary_only:
+        args.no_cpu_baseline = args.no_small_image = args.no_live_traffic = True
+        args.explicit_sweeps = 0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -262,7 +308,7 @@ def main():
 
     # second reported row: plain Jacobi, omega = 1 (updateX_V1's arithmetic), same kernel
     omega1_ms = None
-    if abs(args.omega - 1.0) > 1e-12:
+    if abs(args.omega - 1.0) > 1e-12 and not args.primary_only:
         s.sweeps(sweeps_per_launch * 4, 1.0)
         omega1_ms = s.sweeps(S, 1.0)
 
@@ -270,7 +316,7 @@ def main():
     # into adds as a compiler contracts the reference's expression; bit-identical to the oracle's fma
     # build, NOT to the default arithmetic -- reported beside `value`, never as `value`)
     fma_ms = None
-    if kernel_used != "explicit":
+    if kernel_used != "explicit" and not args.primary_only:
         s.set_tuning("fma", 1)
         s.sweeps(sweeps_per_launch * 4, args.omega)
         fma_ms = s.sweeps(S, args.omega)
@@ -333,8 +379,15 @@ def main():
                                  "operator behind the reference seam, SURVEY.md 8d)",
                         "contract_64B_frac": ach / HBM_PEAK_GBS, "contract_64B_kernel": kernel_used,
                         "contract_64B_launch_us": launch_s * 1e6, "contract_64B_achieved_GBs": ach}
+        live = None
+        if world == 1 and args.batch == 1 and not args.no_live_traffic:
+            live = live_traffic(n, args.kernel, kernel_used)
         tr = traffic_of(kernel_used)
-        if tr:
+        if live:
+            roofline["traffic"], roofline["traffic_source"] = live
+            if tr:
+                roofline["traffic_committed_profile"] = tr["hbm_bytes_per_launch"]
+        elif tr:
             roofline["traffic"] = tr["hbm_bytes_per_launch"]
             roofline["traffic_source"] = tr.get("source")
         if explicit:
