@@ -443,6 +443,7 @@ def main():
                 out["contracted_arithmetic"]["fp64_instr_frac"] = fl / FP64_INSTR_PEAK_T
         if small:
             out["single_image_1024"] = {"value": small[0], "unit": "Mcells*iter/s", "kernel": small[1], "plan": small[2],
+                                        "fp64_instr_frac": FP64_INSTR_PER_CELL[False] * small[0] * 1e6 / 1e12 / FP64_INSTR_PEAK_T,
                                         "sample": "4800 sweeps (best of 3) of ONE 1024x1024 synthetic image (BASELINE config #2's "
                                                   "shape), same physics, one GPU"}
         if world == 1 and not args.no_cpu_baseline:
