@@ -1,0 +1,68 @@
+"""Register / scratch / occupancy budget of the hot kernels, checked on the ISA hipcc emits for gfx950 (no GPU needed:
+`-Rpass-analysis=kernel-resource-usage`).  These numbers ARE the performance model of DESIGN.md section 4 -- waves per SIMD
+decide the FP64 issue rate -- and they move with innocent-looking edits (a `blockDim.x` in the dictionary load cost the
+streaming kernel 22 VGPRs and one wave per SIMD; workgroup tiles with 8 rows per wave spill into the sweep loop), so they
+are pinned here."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+CSRC = os.path.join(ROOT, "effectivediffusivityfvm_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def usage():
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                        "-fno-fast-math", "-fvisibility=hidden", "-Wno-unused-function",
+                        "-Rpass-analysis=kernel-resource-usage", "-c", "-o", os.devnull, "api_solve.hip"],
+                       cwd=CSRC, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" ")[0]] = int(m.group(2))
+    return out
+
+
+def kernels(usage, prefix):
+    got = {k: v for k, v in usage.items() if k.startswith(prefix)}
+    assert got, prefix
+    return got
+
+
+def test_streaming_blocked_kernel_keeps_its_waves(usage):
+    """k_sweep_matfree_tb<T, FMA, GUARD>: T = 8 and 6 at 3 waves per SIMD (<= 168 VGPRs), T = 4 at 4 (<= 128), no AGPR,
+    next to no scratch (the 24 B of T = 8 sit outside the row loop)."""
+    for name, u in kernels(usage, "_ZN4deff18k_sweep_matfree_tbILi8E").items():
+        assert u["Occupancy"] >= 3 and u["VGPRs"] <= 168 and u["AGPRs"] == 0 and u["ScratchSize"] <= 32, (name, u)
+    for name, u in kernels(usage, "_ZN4deff18k_sweep_matfree_tbILi6E").items():
+        assert u["Occupancy"] >= 3 and u["ScratchSize"] == 0, (name, u)
+    for name, u in kernels(usage, "_ZN4deff18k_sweep_matfree_tbILi4E").items():
+        assert u["Occupancy"] >= 4 and u["VGPRs"] <= 128 and u["ScratchSize"] == 0, (name, u)
+    for name, u in kernels(usage, "_ZN4deff18k_sweep_matfree_tbI").items():
+        assert u["LDS"] <= 25 * 1024, (name, u)                 # dictionary only: 3-4 workgroups per CU
+
+
+def test_workgroup_tile_kernel_fits_two_waves_per_simd(usage):
+    """k_sweep_wgtile<T, R, FMA, GUARD>: 8 waves per workgroup = 2 per SIMD = 256 VGPRs; R = 4 and 6 without scratch,
+    R = 7 with at most a few spilled registers (outside the sweep loop); one workgroup's LDS (dictionary + mailbox)."""
+    for R, scratch in ((4, 0), (6, 0), (7, 128)):
+        for T in (4, 8):
+            for name, u in kernels(usage, f"_ZN4deff14k_sweep_wgtileILi{T}ELi{R}E").items():
+                assert u["Occupancy"] >= 2 and u["VGPRs"] <= 256 and u["AGPRs"] == 0 and u["ScratchSize"] <= scratch, (name, u)
+                assert u["LDS"] <= 64 * 1024, (name, u)
+
+
+def test_single_sweep_kernels_are_light(usage):
+    for prefix in ("_ZN4deff16k_sweep_explicitI", "_ZN4deff15k_sweep_matfreeI", "_ZN4deff14k_sweep_scalarI"):
+        for name, u in kernels(usage, prefix).items():
+            assert u["ScratchSize"] == 0 and u["Occupancy"] >= 4, (name, u)
