@@ -87,6 +87,48 @@ def test_stb_fixture_regenerates_from_the_reference(img00000, stb_recorded, tmp_
     assert open(os.path.join(GOLDEN, "00000.jpg"), "rb").read() == open("/root/reference/Deff2DGPU/00000.jpg", "rb").read()
 
 
+def test_jpeg_decoder_byte_equal_to_stb_image_on_random_files(built, tmp_path):
+    """oracle/_ref/stb_dump is the reference's image read -- stbi_load(name,&w,&h,&n,1), Deff2D.cuh:342 -- built from the
+    reference's own stb_image.h (oracle/Makefile, target `ref`; the binary travels to the GPU box).  60 one-component baseline
+    JPEGs of assorted sizes (partial MCUs), contents (two-level, three-level, smooth, noise) and qualities, with and
+    without restart markers, must decode to exactly the same bytes with csrc/driver/jpeg_gray.hpp."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "stb_dump")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("oracle/_ref/stb_dump not built (needs /root/reference at build time)")
+    import effectivediffusivityfvm_amd as pkg
+    from PIL import Image
+    rng = np.random.default_rng(20241022)
+    checked = 0
+    for k in range(60):
+        W, H = int(rng.integers(1, 200)), int(rng.integers(1, 200))
+        kind = k % 4
+        if kind == 0:
+            a = np.where(rng.random((H, W)) < 0.5, 0, 255)
+        elif kind == 1:
+            f = np.kron(rng.random((H // 8 + 1, W // 8 + 1)), np.ones((8, 8)))[:H, :W]
+            a = np.where(f < 0.3, 0, np.where(f < 0.6, 150, 255))
+        elif kind == 2:
+            yy, xx = np.mgrid[0:H, 0:W]
+            a = 127.5 + 127.5 * np.sin(xx / 7.0) * np.cos(yy / 11.0)
+        else:
+            a = rng.random((H, W)) * 255
+        path = tmp_path / f"r{k}.jpg"
+        opts = dict(quality=int(rng.integers(30, 101)))
+        if k % 5 == 0:
+            opts["restart_marker_blocks"] = 3
+        Image.fromarray(a.astype(np.uint8)).save(path, **opts)
+        raw = tmp_path / "out.raw"
+        r = subprocess.run([exe, str(path), str(raw)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        w, h, n = map(int, r.stdout.split())
+        want = np.fromfile(raw, dtype=np.uint8).reshape(h, w)
+        mine = pkg.load_jpeg_gray(path)
+        assert n == 1 and mine.shape == (H, W) == (h, w)
+        assert np.array_equal(mine, want), (k, W, H, opts, int((mine != want).sum()))
+        checked += 1
+    assert checked == 60
+
+
 def test_jpeg_decoder_rejects_what_the_reference_rejects(built, tmp_path):
     import effectivediffusivityfvm_amd as pkg
     from PIL import Image
