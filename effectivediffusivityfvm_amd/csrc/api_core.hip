@@ -123,6 +123,8 @@ try {
     for (void *p : bufs) if (p) (void)hipFree(p);
     if (c->mf_host) (void)hipHostFree(c->mf_host);
     if (c->q) (void)hipFree(c->q);
+    if (c->res_flags) (void)hipFree(c->res_flags);
+    if (c->res_abort) (void)hipFree(c->res_abort);
     if (c->q_host) (void)hipHostFree(c->q_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -212,6 +214,8 @@ try {
     else if (!strcmp(key, "tb_LY")) c->tb_LY = value;
     else if (!strcmp(key, "tb_impl")) c->tb_impl = value > 2 ? 0 : value;
     else if (!strcmp(key, "tb_R")) c->tb_R = value;
+    else if (!strcmp(key, "tb_resident")) c->tb_resident = value ? 1 : 0;
+    else if (!strcmp(key, "tb_coop")) c->tb_coop = value ? 1 : 0;
     else if (!strcmp(key, "flux_reduce")) c->flux_reduce = value > 2 ? 0 : value;
     else if (!strcmp(key, "tb_NW")) c->tb_NW = value;
     else if (!strcmp(key, "dict")) c->dict_enabled = value ? 1 : 0;
@@ -235,6 +239,7 @@ try {
     else if (!strcmp(key, "tb_blocks")) *value = c->plan_blocks;
     else if (!strcmp(key, "tb_impl")) *value = c->plan_impl;
     else if (!strcmp(key, "tb_R")) *value = c->plan_R;
+    else if (!strcmp(key, "tb_resident")) *value = c->plan_resident;
     else if (!strcmp(key, "tb_NW")) *value = c->plan_NW;
     else return fail(DEFF_EINVAL, "unknown plan key '%s'", key);
     return DEFF_OK;
@@ -599,6 +604,7 @@ DEFF_API_CATCH
 // buffer was current at that moment; bring every image's newest field into x[cur].
 int consolidate(deff_ctx *c)
 {
+    TRY(resident_check(c));
     if (!c->masked) return DEFF_OK;                  // nothing frozen: every image is current in x[cur]
     for (int k = 0; k < c->nimg; ++k)
         if (c->buf_of[k] != (uint8_t)c->cur) {
@@ -651,6 +657,7 @@ try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     TRY(use_device(c));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    TRY(resident_check(c));
     return DEFF_OK;
 }
 DEFF_API_CATCH

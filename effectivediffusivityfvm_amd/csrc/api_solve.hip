@@ -6,6 +6,7 @@
 #include "kernels_sweep.hpp"
 #include "kernels_tb.hpp"
 #include "kernels_wgtile.hpp"
+#include <mutex>
 
 // ----------------------------------------------------------- sweeps -------
 
@@ -80,6 +81,99 @@ static int wgt_resident_blocks(const deff_ctx *c, int T, int R, bool fma, bool g
 #undef OCC_CALL
     if (per_cu < 1) per_cu = 1;
     *resident = per_cu * cus;
+    return DEFF_OK;
+}
+
+template <int T, int R, bool F, bool G>
+static int wgr_occ(int *per_cu)
+{
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_sweep_wgres<T, R, F, G>, WGT_WAVES * 64, 0));
+    return DEFF_OK;
+}
+
+static int wgr_resident_blocks(const deff_ctx *c, int T, int R, bool fma, bool guard, int *resident)
+{
+    int per_cu = 0, cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+#define OCC_CALL(T_, R_, C_, G_) TRY((wgr_occ<T_, R_, C_, G_>(&per_cu)))
+    WGT_DISPATCH(T, R, fma, guard, OCC_CALL);
+#undef OCC_CALL
+    *resident = per_cu * cus;
+    return DEFF_OK;
+}
+
+// Resident launches of this process, chained per device: a resident kernel must have all its workgroups on the chip to
+// make progress, so two of them (two contexts on one GPU: deff2d --devices 0,0, a thread pool) must never be dispatched
+// side by side -- each waits for the previous one's end.  Finite kernels of other streams only delay a resident launch.
+static std::mutex g_res_mu;
+static hipEvent_t g_res_ev[64];
+static bool g_res_has[64];
+
+static hipError_t resident_chain_begin(const deff_ctx *c)
+{
+    const int d = c->device;
+    if (d < 0 || d >= 64) return hipSuccess;
+    if (!g_res_has[d]) {
+        hipError_t e = hipEventCreateWithFlags(&g_res_ev[d], hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        g_res_has[d] = true;
+        return hipSuccess;                                          // nothing to wait for yet
+    }
+    return hipStreamWaitEvent(c->stream, g_res_ev[d], 0);
+}
+
+static hipError_t resident_chain_end(const deff_ctx *c)
+{
+    const int d = c->device;
+    if (d < 0 || d >= 64 || !g_res_has[d]) return hipSuccess;
+    return hipEventRecord(g_res_ev[d], c->stream);
+}
+
+template <int T, int R, bool F, bool G>
+static hipError_t launch_wgres(deff_ctx *c, const SweepPlan &pl, double *xa, double *xb, int npass, unsigned base)
+{
+    unsigned long long *stamps = c->tb_stamps;
+    unsigned xbytes = (unsigned)(c->n * sizeof(double));
+    const double *lut = c->lut;
+    const uint16_t *code = c->code;
+    int nx = c->nx, ny = c->mesh_ny, img_stride = c->ny, dom_lo = c->dom_lo, own_lo = pl.own_lo, own_h = pl.own_h;
+    int cpi = pl.tcpi, ly = pl.LY, ntx = pl.ntx, gy = pl.tgy, xmajor = c->tb_xmajor;
+    int allb = (c->lut_allb || c->nx != c->nxt) ? 1 : 0, nrows = c->lut_nrows, shift = pl.shift;
+    const uint8_t *mask = c->masked ? c->active : nullptr;
+    double omw = pl.omw;
+    unsigned *flags = c->res_flags, *abort_flag = c->res_abort;
+    if (!c->tb_coop || c->coop_launch <= 0) {
+        std::lock_guard<std::mutex> lock(g_res_mu);
+        hipError_t e = resident_chain_begin(c);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_sweep_wgres<T, R, F, G>), dim3(pl.tblocks), dim3(WGT_WAVES * 64), 0, c->stream, lut, code, xa,
+                           xb, nx, ny, img_stride, dom_lo, own_lo, own_h, cpi, ly, mask, ntx, gy, xmajor, allb, nrows, shift,
+                           omw, npass, flags, base, abort_flag, xbytes, stamps);
+        e = hipPeekAtLastError();
+        if (e != hipSuccess) return e;
+        return resident_chain_end(c);
+    }
+    void *args[] = {&lut, &code, &xa, &xb, &nx, &ny, &img_stride, &dom_lo, &own_lo, &own_h, &cpi, &ly, &mask, &ntx, &gy,
+                    &xmajor, &allb, &nrows, &shift, &omw, &npass, &flags, &base, &abort_flag, &xbytes, &stamps};
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&k_sweep_wgres<T, R, F, G>), dim3(pl.tblocks),
+                                      dim3(WGT_WAVES * 64), args, 0, c->stream);
+}
+
+// Did a resident launch give up?  Reads the flag (one 4-byte copy + a stream synchronisation) only when such a launch was
+// enqueued since the last look.  A raised flag means some tile stopped updating: the field is not a Jacobi iterate.
+int resident_check(deff_ctx *c)
+{
+    if (!c->res_pending) return DEFF_OK;
+    unsigned h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, c->res_abort, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->res_pending = false;
+    if (h) {
+        HIP_TRY(hipMemsetAsync(c->res_abort, 0, sizeof h, c->stream));
+        c->have_field = false;
+        return fail(DEFF_EHIP, "resident passes aborted: a workgroup waited more than 2 s for a neighbouring tile "
+                               "(the field is invalid; set tuning tb_resident = 0 to launch every pass separately)");
+    }
     return DEFF_OK;
 }
 
@@ -266,9 +360,36 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
                 pl->tblocks = (int)(((tiles + 7) / 8) * 8);
                 if (pl->tblocks > resident) pl->tblocks = resident >= 8 ? resident / 8 * 8 : 8;
                 pl->guard = c->lut_guard;
+                // Resident passes (k_sweep_wgres): every tile on the chip at once, a whole context (no slab, whose halo
+                // rows change between passes from outside), tiles at least T rows tall (a tile's halo must end inside its
+                // immediate neighbours: they are the ones it waits for), no per-tile diagnostics.
+                pl->resident = false;
+                if (c->tb_resident && !c->slab && pl->band_h <= 0 &&
+                    (pl->LY >= T || pl->tcpi == 1) &&
+                    c->n * sizeof(double) < ((size_t)1 << 31)) {      // 32-bit buffer offsets
+                    int res = 0;
+                    TRY(wgr_resident_blocks(c, T, pl->R, pl->fma, c->lut_guard, &res));
+                    if (c->coop_launch < 0)
+                        HIP_TRY(hipDeviceGetAttribute(&c->coop_launch, hipDeviceAttributeCooperativeLaunch, c->device));
+                    if ((long)((tiles + 7) / 8) * 8 <= res) {
+                        pl->resident = true;
+                        pl->tblocks = (int)(((tiles + 7) / 8) * 8);
+                        if (c->res_flags_n < (size_t)tiles) {
+                            if (c->res_flags) { HIP_TRY(hipFree(c->res_flags)); c->res_flags = nullptr; }
+                            TRY(dev_alloc(&c->res_flags, (size_t)tiles * WGR_FLAG_STRIDE));
+                            HIP_TRY(hipMemsetAsync(c->res_flags, 0, sizeof(unsigned) * tiles * WGR_FLAG_STRIDE, c->stream));
+                            c->res_flags_n = (size_t)tiles;
+                        }
+                        if (!c->res_abort) {
+                            TRY(dev_alloc(&c->res_abort, 1));
+                            HIP_TRY(hipMemsetAsync(c->res_abort, 0, sizeof(unsigned), c->stream));
+                        }
+                    }
+                }
                 if (pl->band_h <= 0) {
                     c->plan_T = pl->T; c->plan_LY = pl->LY; c->plan_ntx = pl->ntx; c->plan_cpi = pl->tcpi;
                     c->plan_blocks = pl->tblocks; c->plan_impl = 2; c->plan_R = pl->R; c->plan_NW = pl->NW;
+                    c->plan_resident = pl->resident ? 1 : 0;
                 }
             } else {
             pl->impl = 1;
@@ -308,7 +429,7 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             if (pl->tblocks > resident) pl->tblocks = resident >= 8 ? resident / 8 * 8 : 8;
             if (!pl->T_override && pl->band_h <= 0) {    // the remainder plan of a slab (T = 1) and band plans are not "the" plan
                 c->plan_T = pl->T; c->plan_LY = pl->LY; c->plan_ntx = pl->ntx; c->plan_cpi = pl->tcpi;
-                c->plan_blocks = pl->tblocks; c->plan_impl = 1; c->plan_R = 0;
+                c->plan_blocks = pl->tblocks; c->plan_impl = 1; c->plan_R = 0; c->plan_resident = 0;
             }
             // the reference's non-zero link test matters only when a phase cannot diffuse
             pl->guard = c->lut_guard;
@@ -427,6 +548,24 @@ void launch_tb_pass(deff_ctx *c, const SweepPlan &pl)
 // n sweeps: as many T-sweep passes as fit, the rest one at a time.
 void enqueue_sweeps(deff_ctx *c, const SweepPlan &pl, int64_t n)
 {
+    if (pl.kernel == DEFF_KERNEL_MATFREE_TB && pl.impl == 2 && pl.resident && n >= 2 * pl.T) {
+        // all whole passes in launches of up to 4 096 passes (tens of milliseconds each)
+        int64_t np = n / pl.T;
+        while (np > 0) {
+            const int chunk = (int)(np < 4096 ? np : 4096);
+            hipError_t e = hipSuccess;
+#define LAUNCH_WGR(T_, R_, C_, G_) e = launch_wgres<T_, R_, C_, G_>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch)
+            WGT_DISPATCH(pl.T, pl.R, pl.fma, pl.guard, LAUNCH_WGR);
+#undef LAUNCH_WGR
+            if (e != hipSuccess) break;                            // left in hipGetLastError() for the caller
+            c->res_epoch += (unsigned)chunk;
+            c->res_pending = true;
+            c->cur ^= (chunk & 1);
+            np -= chunk;
+            n -= (int64_t)chunk * pl.T;
+            ++c->last_launches;
+        }
+    }
     if (pl.kernel == DEFF_KERNEL_MATFREE_TB) {
         while (n >= pl.T) { enqueue_tb_pass(c, pl); n -= pl.T; ++c->last_launches; }
     }
@@ -448,6 +587,7 @@ try {
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
     if (ms) HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    TRY(resident_check(c));
     return DEFF_OK;
 }
 DEFF_API_CATCH
@@ -458,6 +598,7 @@ int flux_rows(deff_ctx *c, bool need_rows)
 {
     if (!c->have_walls)
         return fail(DEFF_ESTATE, "wall diffusivities unknown: pass D to deff_set_system() or assemble on the device");
+    TRY(resident_check(c));
     hipLaunchKernelGGL(k_wall_flux, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, c->x[c->cur], c->Dl,
                        c->Dr, c->nx, c->nxt, c->rows, c->dx, c->CL, c->CR, c->mf);
     HIP_TRY(hipGetLastError());
@@ -808,7 +949,8 @@ try {
     if (!out) return DEFF_OK;
     HIP_TRY(hipMalloc((void **)&c->tb_stamps, sizeof(unsigned long long) * 2 * n));
     HIP_TRY(hipMemsetAsync(c->tb_stamps, 0, sizeof(unsigned long long) * 2 * n, c->stream));
-    enqueue_tb_pass(c, pl);
+    if (pl.impl == 2 && pl.resident && pl.T == 8) enqueue_sweeps(c, pl, 3 * pl.T);   // k_sweep_wgres: 12 stamps per tile, 3 passes
+    else enqueue_tb_pass(c, pl);
     hipError_t e = hipMemcpyAsync(out, c->tb_stamps, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(c->tb_stamps);

@@ -147,6 +147,21 @@ struct deff_ctx {
     // form of a temporally blocked pass: 0 = chosen by the planner, 1 = streaming (kernels_tb.hpp: one wave per tile),
     // 2 = workgroup tiles (kernels_wgtile.hpp: 8 waves per tile, rows resident in registers); tb_R = rows per wave there
     int tb_impl = 0, tb_R = 0, tb_NW = 0;
+    // resident passes (kernels_wgtile.hpp, k_sweep_wgres): when every tile of the context is on the chip at once, all the
+    // passes between two checks are ONE launch whose tiles keep their matrix rows and owned cells in registers and wait
+    // for their neighbours only.  tb_resident: 1 = whenever the tiles are co-resident (default), 0 = never (one launch per
+    // pass).  tb_coop: 0 = plain launch (default): the grid fits the chip by the occupancy query, resident launches of one
+    // process are chained per device (api_solve.hip) so that two of them never share the chip, and every wait is bounded;
+    // 1 = hipLaunchCooperativeKernel, which makes the runtime vouch for co-residency -- not the default because ROCm
+    // 7.2's teardown segfaults at process exit once several host threads have launched cooperatively (deff2d --devices).
+    int tb_resident = 1, tb_coop = 0;
+    int plan_resident = 0;                       // the last plan used resident passes
+    unsigned *res_flags = nullptr;               // per tile: passes completed (epoch counter)
+    size_t res_flags_n = 0;
+    unsigned res_epoch = 0;
+    unsigned *res_abort = nullptr;               // raised by a workgroup whose wait for a neighbour ran out
+    bool res_pending = false;                    // a resident launch was enqueued since the flag was last read
+    int coop_launch = -1;                        // hipDeviceAttributeCooperativeLaunch, cached
     int fma = 0;                                 // contracted arithmetic (kernels_sweep.hpp), opt-in
     int tb_xmajor = 1;                           // wave-tile numbering of the temporally blocked kernel
     int64_t last_launches = 0;                   // sweep-kernel launches of the last deff_sweeps()/deff_solve()
@@ -253,6 +268,7 @@ struct SweepPlan {
     int T_override = 0;                                   // slab mode plans a T = 1 pass for remainders
     bool guard = false;
     int impl = 1, R = 0, NW = 8;                          // 1 = streaming kernel, 2 = workgroup tiles of NW waves x R rows
+    bool resident = false;                                // impl 2 only: all passes of a batch in one launch (k_sweep_wgres)
     // rows the plan updates: band_h > 0 restricts it to the band [band_lo, band_lo + band_h) of the context's owned rows
     // (input); own_lo / own_h are what the planner resolved (output, passed to the kernels)
     int band_lo = 0, band_h = 0, own_lo = 0, own_h = 0;
@@ -275,4 +291,5 @@ void enqueue_sweep(deff_ctx *c, const SweepPlan &pl);
 void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl);
 void launch_tb_pass(deff_ctx *c, const SweepPlan &pl);   // the same launch without flipping x[cur]
 void enqueue_sweeps(deff_ctx *c, const SweepPlan &pl, int64_t n);
+int resident_check(deff_ctx *c);                         // did a resident launch give up waiting?  (synchronises if one is pending)
 int flux_rows(deff_ctx *c, bool need_rows = true);

@@ -126,6 +126,82 @@ __device__ __forceinline__ void wgt_rows(const WgtCoef *const (&k)[NROWS], const
     for (int q = 0; q < NROWS; ++q) out[q] = make_double2(sg[2 * q], sg[2 * q + 1]);
 }
 
+// The T sweeps of a wave's R rows, in place, from coefficients held in registers.  Per sweep: publish the first and last
+// row; update the interior rows 1 .. R-2 (they need nothing from another wave), two at a time; barrier; update rows 0 and
+// R-1 from the neighbours' edge rows.  A wave some of whose rows no owned cell depends on any more (the tile's outermost
+// waves) takes the row-by-row path with a wave-uniform test per row.  Every wave of the workgroup must call this (one
+// __syncthreads per sweep); `par` is the mailbox parity, toggled every sweep (also across tiles and passes).
+template <int T, int R, bool FMA, bool GUARD, bool WALL>
+__device__ __forceinline__ void wgt_sweeps(double2 (&xr)[R], const WgtCoef (&k)[R], const double2 (&bb)[WALL ? R : 1],
+                                           double2 (&edge)[2][WGT_WAVES][2][64], int &par, const int wave, const int lane,
+                                           const int w0, const int ry0, const int ry1, const int row_lo, const int row_hi,
+                                           const double omw, unsigned long long *st)
+{
+    constexpr int NW = WGT_WAVES;
+    const double2 zero = make_double2(0.0, 0.0);
+    auto one = [&](const int r, const double2 n_, const double2 c_, const double2 s_) __attribute__((always_inline)) {
+        const WgtCoef *const kp[1] = {&k[r]};
+        const double2 b1[1] = {WALL ? bb[WALL ? r : 0] : zero};
+        const double2 n1[1] = {n_}, c1[1] = {c_}, s1[1] = {s_};
+        double2 o[1];
+        wgt_rows<1, GUARD, FMA>(kp, b1, n1, c1, s1, omw, o);
+        return o[0];
+    };
+    auto two = [&](const int ra, const int rb, const double2 na, const double2 ca, const double2 sa, const double2 nb,
+                   const double2 cb, const double2 sb, double2 &oa, double2 &ob) __attribute__((always_inline)) {
+        const WgtCoef *const kp[2] = {&k[ra], &k[rb]};
+        const double2 b2[2] = {WALL ? bb[WALL ? ra : 0] : zero, WALL ? bb[WALL ? rb : 0] : zero};
+        const double2 n2[2] = {na, nb}, c2[2] = {ca, cb}, s2[2] = {sa, sb};
+        double2 o[2];
+        wgt_rows<2, GUARD, FMA>(kp, b2, n2, c2, s2, omw, o);
+        oa = o[0];
+        ob = o[1];
+    };
+#pragma unroll 1
+    for (int t = 1; t <= T; ++t) {
+        // level t is needed on [ry0 - (T - t), ry1 + (T - t)) inside the mesh
+        const int need_lo = max(ry0 - (T - t), row_lo), need_hi = min(ry1 + (T - t), row_hi);
+        edge[par][wave][0][lane] = xr[0];
+        edge[par][wave][1][lane] = xr[R - 1];
+        const bool any = w0 + R > need_lo && w0 < need_hi;
+        const bool full = w0 >= need_lo && w0 + R <= need_hi;
+        if (full) {
+            const double2 old1 = xr[1], oldp = xr[R - 2];
+            double2 prev = xr[0];
+#pragma unroll
+            for (int r = 1; r + 1 <= R - 2; r += 2) {
+                const double2 ca = xr[r], cb = xr[r + 1];
+                two(r, r + 1, prev, ca, cb, ca, cb, xr[r + 2], xr[r], xr[r + 1]);
+                prev = cb;
+            }
+            if constexpr ((R - 2) % 2 == 1) xr[R - 2] = one(R - 2, prev, xr[R - 2], xr[R - 1]);
+            __syncthreads();
+            const double2 top = (wave > 0) ? edge[par][wave - 1][1][lane] : zero;
+            const double2 bot = (wave < NW - 1) ? edge[par][wave + 1][0][lane] : zero;
+            two(0, R - 1, top, xr[0], old1, oldp, xr[R - 1], bot, xr[0], xr[R - 1]);
+        } else if (any) {
+            const double2 old1 = xr[1], oldp = xr[R - 2];
+            double2 prev = xr[0];
+#pragma unroll
+            for (int r = 1; r <= R - 2; ++r) {
+                const double2 cur = xr[r];
+                const int rr = w0 + r;
+                if (rr >= need_lo && rr < need_hi) xr[r] = one(r, prev, cur, xr[r + 1]);
+                prev = cur;
+            }
+            __syncthreads();
+            const double2 top = (wave > 0) ? edge[par][wave - 1][1][lane] : zero;
+            const double2 bot = (wave < NW - 1) ? edge[par][wave + 1][0][lane] : zero;
+            if (w0 >= need_lo && w0 < need_hi) xr[0] = one(0, top, xr[0], old1);
+            if (w0 + R - 1 >= need_lo && w0 + R - 1 < need_hi) xr[R - 1] = one(R - 1, oldp, xr[R - 1], bot);
+        } else {
+            __syncthreads();
+        }
+        par ^= 1;
+        if (st) st[2 + t] = wall_clock64();
+    }
+}
+
 // grid: persistent workgroups of 8 waves; tiles (strip tx, row tile ty) numbered like the streaming
 // kernel's wave tiles (x-major: neighbouring strips adjacent; per XCD a contiguous run).
 // Geometry parameters as k_sweep_matfree_tb: image k of a stack has its mesh rows at
@@ -226,10 +302,7 @@ __global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgtile(const double
             st[2] = wall_clock64();
         }
 
-        // The T sweeps of this wave's R rows, in place, from coefficients held in registers for the whole pass.  Per sweep:
-        // publish the first and last row; update the interior rows 1 .. R-2 (they need nothing from another wave), two at a
-        // time; barrier; update rows 0 and R-1 from the neighbours' edge rows.  A wave some of whose rows no owned cell
-        // depends on any more (the tile's outermost waves) takes the row-by-row path with a wave-uniform test per row.
+        // the T sweeps of this wave's R rows, from coefficients looked up once (wgt_sweeps)
         auto tile = [&](auto wall_tag) __attribute__((always_inline)) {
             constexpr bool WALL = decltype(wall_tag)::value;
             WgtCoef k[R];
@@ -240,67 +313,7 @@ __global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgtile(const double
                 wgt_lookup<WALL>(lut, cc[r], k[r], b_);
                 if constexpr (WALL) bb[r] = b_;
             }
-            auto one = [&](const int r, const double2 n_, const double2 c_, const double2 s_) __attribute__((always_inline)) {
-                const WgtCoef *const kp[1] = {&k[r]};
-                const double2 b1[1] = {WALL ? bb[WALL ? r : 0] : zero};
-                const double2 n1[1] = {n_}, c1[1] = {c_}, s1[1] = {s_};
-                double2 o[1];
-                wgt_rows<1, GUARD, FMA>(kp, b1, n1, c1, s1, omw, o);
-                return o[0];
-            };
-            auto two = [&](const int ra, const int rb, const double2 na, const double2 ca, const double2 sa, const double2 nb,
-                           const double2 cb, const double2 sb, double2 &oa, double2 &ob) __attribute__((always_inline)) {
-                const WgtCoef *const kp[2] = {&k[ra], &k[rb]};
-                const double2 b2[2] = {WALL ? bb[WALL ? ra : 0] : zero, WALL ? bb[WALL ? rb : 0] : zero};
-                const double2 n2[2] = {na, nb}, c2[2] = {ca, cb}, s2[2] = {sa, sb};
-                double2 o[2];
-                wgt_rows<2, GUARD, FMA>(kp, b2, n2, c2, s2, omw, o);
-                oa = o[0];
-                ob = o[1];
-            };
-#pragma unroll 1
-            for (int t = 1; t <= T; ++t) {
-                // level t is needed on [ry0 - (T - t), ry1 + (T - t)) inside the mesh
-                const int need_lo = max(ry0 - (T - t), row_lo), need_hi = min(ry1 + (T - t), row_hi);
-                edge[par][wave][0][lane] = xr[0];
-                edge[par][wave][1][lane] = xr[R - 1];
-                const bool any = w0 + R > need_lo && w0 < need_hi;
-                const bool full = w0 >= need_lo && w0 + R <= need_hi;
-                if (full) {
-                    const double2 old1 = xr[1], oldp = xr[R - 2];
-                    double2 prev = xr[0];
-#pragma unroll
-                    for (int r = 1; r + 1 <= R - 2; r += 2) {
-                        const double2 ca = xr[r], cb = xr[r + 1];
-                        two(r, r + 1, prev, ca, cb, ca, cb, xr[r + 2], xr[r], xr[r + 1]);
-                        prev = cb;
-                    }
-                    if constexpr ((R - 2) % 2 == 1) xr[R - 2] = one(R - 2, prev, xr[R - 2], xr[R - 1]);
-                    __syncthreads();
-                    const double2 top = (wave > 0) ? edge[par][wave - 1][1][lane] : zero;
-                    const double2 bot = (wave < NW - 1) ? edge[par][wave + 1][0][lane] : zero;
-                    two(0, R - 1, top, xr[0], old1, oldp, xr[R - 1], bot, xr[0], xr[R - 1]);
-                } else if (any) {
-                    const double2 old1 = xr[1], oldp = xr[R - 2];
-                    double2 prev = xr[0];
-#pragma unroll
-                    for (int r = 1; r <= R - 2; ++r) {
-                        const double2 cur = xr[r];
-                        const int rr = w0 + r;
-                        if (rr >= need_lo && rr < need_hi) xr[r] = one(r, prev, cur, xr[r + 1]);
-                        prev = cur;
-                    }
-                    __syncthreads();
-                    const double2 top = (wave > 0) ? edge[par][wave - 1][1][lane] : zero;
-                    const double2 bot = (wave < NW - 1) ? edge[par][wave + 1][0][lane] : zero;
-                    if (w0 >= need_lo && w0 < need_hi) xr[0] = one(0, top, xr[0], old1);
-                    if (w0 + R - 1 >= need_lo && w0 + R - 1 < need_hi) xr[R - 1] = one(R - 1, oldp, xr[R - 1], bot);
-                } else {
-                    __syncthreads();
-                }
-                par ^= 1;
-                if (st) st[2 + t] = wall_clock64();
-            }
+            wgt_sweeps<T, R, FMA, GUARD, WALL>(xr, k, bb, edge, par, wave, lane, w0, ry0, ry1, row_lo, row_hi, omw, st);
         };
         if (wall) tile(TbTag<true>{});
         else tile(TbTag<false>{});
@@ -315,6 +328,202 @@ __global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgtile(const double
         kk += nper;
         valid = kk < per && open_tile(kk);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Resident form: when ALL tiles of the context are on the chip at once (one tile per workgroup, every workgroup
+// resident: one 1024^2 image is 234 tiles on 256 CUs), the launch need not end after T sweeps.  A workgroup keeps its
+// tile's MATRIX ROWS in registers over `npass` passes and only re-reads the field (its neighbours have changed the
+// halo), so a pass costs neither a launch gap (~1.7 us), nor the dictionary fetch, nor the 70 lookups per lane of its
+// first sweep.  Between passes a tile waits for its (up to 8) neighbours only -- no grid-wide barrier:
+//   pass p reads buffer p&1 and writes the other one; after its stores a workgroup releases them at agent scope and
+//   publishes flags[tile] = base + p + 1; before re-reading the field for pass p >= 1 it waits until every
+//   neighbour's flag has reached base + p, then acquires.  (Write-after-read is covered by the same flags: a tile
+//   overwrites buffer p&1 at the end of pass p + 1, which it only starts once its neighbours have finished pass p, i.e.
+//   are done reading that buffer.)  Pass 0 needs no wait: the launch boundary orders it after everything before.
+// Forward progress: the launch is cooperative (hipLaunchCooperativeKernel refuses a grid that is not co-resident), and
+// every wait is bounded -- a lane that has polled for WGR_TIMEOUT of the 100 MHz wall clock, or that sees *abort_flag set,
+// raises *abort_flag and its workgroup returns; so does, within one poll, every workgroup waiting anywhere.  The host
+// checks the flag at its next synchronisation and fails the call (api_solve.hip).
+// Same arithmetic, same tiles, same results bit for bit as npass launches of k_sweep_wgtile.
+constexpr unsigned long long WGR_TIMEOUT = 200000000ull;       // 2 s
+constexpr int WGR_FLAG_STRIDE = 64;                            // unsigneds between two tiles' flags: one 256-byte block each, so that
+                                                               // ~2 000 polling lanes do not queue on a handful of cache lines
+
+// The field between passes of one launch travels through device-coherent accesses: 16-byte buffer loads / stores with
+// sc1 set (what an agent-scope relaxed atomic compiles to on gfx942/gfx950: the store is written through, the load is
+// served from the coherence point, neither needs a cache-wide write-back or invalidate).  Measured on one 1024^2 image:
+// plain accesses + agent-scope release / acquire fences (buffer_wbl2 / buffer_inv sc1 by every wave) 63 us per pass;
+// 8-byte sc1 accesses of whole tiles 16.6 us (2.6 us of it the re-read: twice 8 MB from beyond L2); halo-only 16-byte
+// accesses: see DESIGN.md.
+typedef unsigned int wgr_u4 __attribute__((ext_vector_type(4)));
+constexpr int WGR_SC1 = 16;                                    // aux bit 4 of the raw buffer intrinsics on gfx94x/gfx950
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wgr_rsrc(double *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000);
+}
+// address = base + voff (per lane) + soff (wave-uniform, an SGPR: the R row addresses of a wave cost ONE VGPR)
+__device__ __forceinline__ double2 wgr_ld2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const wgr_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, WGR_SC1);
+    double2 d;
+    __builtin_memcpy(&d, &v, 16);
+    return d;
+}
+__device__ __forceinline__ void wgr_st2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double2 d)
+{
+    wgr_u4 v;
+    __builtin_memcpy(&v, &d, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, WGR_SC1);
+}
+
+template <int T, int R, bool FMA, bool GUARD>
+__global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgres(const double *__restrict__ lut_g,
+                                                                   const uint16_t *__restrict__ code, double *xa,
+                                                                   double *xb, int nx, int ny, int img_stride,
+                                                                   int dom_lo, int own_lo, int own_h, int cpi, int ly,
+                                                                   const uint8_t *__restrict__ active, int ntx, int gy,
+                                                                   int xmajor, int allb, int nrows, int shift,
+                                                                   double omw, int npass, unsigned *flags,
+                                                                   unsigned base, unsigned *abort_flag,
+                                                                   unsigned xbytes,
+                                                                   unsigned long long *__restrict__ stamps)
+{
+    constexpr int NW = WGT_WAVES;
+    static_assert(T >= 1 && T <= 8 && R >= 4, "unsupported tile");
+    static_assert(wgt_rows_owned(T, R) >= 1, "tile owns no row");
+    constexpr int HW = (T + 1) & ~1;
+    constexpr int WOUT = TB_COLS - 2 * HW;
+
+    __shared__ double lut[LUT_DOUBLES];
+    __shared__ double2 edge[2][NW][2][64];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned total = (unsigned)ntx * (unsigned)gy;
+    const unsigned per = (total + 7u) / 8u;
+    const double2 zero = make_double2(0.0, 0.0);
+    int par = 0;
+
+    // ONE tile per workgroup, numbered like k_sweep_wgtile's first round
+    const unsigned kk = blockIdx.x >> 3;
+    const unsigned bt = (blockIdx.x & 7u) * per + kk;
+    if (kk >= per || bt >= total) return;                          // workgroup-uniform
+    const int tx = xmajor ? (int)(bt % (unsigned)ntx) : (int)(bt / (unsigned)gy);
+    const int bty = xmajor ? (int)(bt / (unsigned)ntx) : (int)(bt % (unsigned)gy);
+    const int img = bty / cpi;
+    if (active && !active[img]) return;                            // frozen image: all its tiles return, nobody waits for them
+    const int row_lo = dom_lo + img * img_stride, row_hi = row_lo + ny;
+    const int own0 = own_lo + img * img_stride;
+    const int ry0 = own0 + (bty - img * cpi) * ly;
+    const int ry1 = min(ry0 + ly, own0 + own_h);
+    const int w0 = ry0 - T + wave * R;
+    const int ld_lo = max(ry0 - T, row_lo), ld_hi = min(ry1 + T, row_hi);
+    const int col = tx * WOUT - shift + 2 * lane;
+    const bool in_x = col >= 0 && col < nx;
+    const int out_lo = (tx == 0) ? 0 : tx * WOUT - shift + HW;
+    const int out_hi = (tx == ntx - 1) ? nx : tx * WOUT - shift + TB_COLS - HW;
+    const bool st_x = in_x && (col >= out_lo) && (col < out_hi);
+    const bool wall = allb || tx == 0 || tx == ntx - 1;
+
+    // diagnostics (tools/wgt_stamps.py --resident): per tile 12 clocks = entry, then for passes 0..2 {halo rows in, swept,
+    // stored and released}, pass 0's "waited" slot holding the end of the lookups
+    unsigned long long *st = (stamps && threadIdx.x == 0) ? stamps + (size_t)bt * 12 : nullptr;
+    if (st) st[0] = wall_clock64();
+    // the neighbour this lane polls between passes (lanes 0..7 of wave 0; -1: none -- a wall, or another image)
+    int nb = -1;
+    if (threadIdx.x < 8) {
+        const int q = (int)threadIdx.x < 4 ? (int)threadIdx.x : (int)threadIdx.x + 1;    // 0..8 without the centre
+        const int tx2 = tx + q % 3 - 1, by2 = bty + q / 3 - 1;
+        if (tx2 >= 0 && tx2 < ntx && by2 >= img * cpi && by2 < (img + 1) * cpi)
+            nb = xmajor ? by2 * ntx + tx2 : tx2 * gy + by2;
+    }
+
+    double2 xr[R];
+    unsigned cc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int rr = w0 + r;
+        const bool ok = in_x && rr >= ld_lo && rr < ld_hi;
+        const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col : 0);
+        const double2 vx = ld2(xa + p);
+        const unsigned vc = *reinterpret_cast<const uint32_t *>(code + p);
+        xr[r] = ok ? vx : zero;
+        cc[r] = ok ? vc : 0u;
+    }
+    load_lut<NW * 64>(lut, lut_g, nrows);
+
+    auto passes = [&](auto wall_tag) __attribute__((always_inline)) {
+        constexpr bool WALL = decltype(wall_tag)::value;
+        WgtCoef k[R];
+        double2 bb[WALL ? R : 1];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double2 b_;
+            wgt_lookup<WALL>(lut, cc[r], k[r], b_);
+            if constexpr (WALL) bb[r] = b_;
+        }
+        const __amdgpu_buffer_rsrc_t ra = wgr_rsrc(xa, xbytes), rb = wgr_rsrc(xb, xbytes);
+        // what a tile exchanges with its neighbours: its halo (read) and the rim of its owned cells (written) -- the owned
+        // cells themselves never leave the registers between two passes of a launch
+        const bool halo_x = in_x && !st_x;                         // this lane's two columns belong to a neighbouring strip
+        const bool rim_x = st_x && (col < out_lo + HW || col >= out_hi - HW);
+        // byte offset of this lane's cell pair within a row; the row's offset is wave-uniform (rows above the array and lanes
+        // left of it are never addressed: they fail `ok` / `st_x`; the buffer's range check sees voff + soff unwrapped)
+        const unsigned voff = (unsigned)col * 8u;
+#pragma unroll 1
+        for (int p = 0; p < npass; ++p) {
+            const __amdgpu_buffer_rsrc_t src = (p & 1) ? rb : ra, dst = (p & 1) ? ra : rb;
+            const bool last = p + 1 == npass;
+            if (p > 0) {
+                int bad = 0;
+                if (nb >= 0) {
+                    const unsigned want = base + (unsigned)p;
+                    const unsigned long long t0 = wall_clock64();
+                    unsigned polls = 0;
+                    while ((int)(__hip_atomic_load(flags + (size_t)nb * WGR_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if ((++polls & 31u) == 0u &&
+                            (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                             wall_clock64() - t0 > WGR_TIMEOUT)) {
+                            __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            bad = 1;
+                            break;
+                        }
+                    }
+                }
+                if (__syncthreads_or(bad)) return;                 // workgroup-uniform: decided by wave 0's polling lanes
+                if (st && p < 3) st[4 * p] = wall_clock64();
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int rr = w0 + r;
+                    const bool ok = in_x && rr >= ld_lo && rr < ld_hi;
+                    if (ok && (halo_x || rr < ry0 || rr >= ry1))
+                        xr[r] = wgr_ld2(src, voff, (unsigned)(rr * nx) * 8u);
+                }
+            }
+            if (st && p < 3) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                st[4 * p + 1] = wall_clock64();
+            }
+            wgt_sweeps<T, R, FMA, GUARD, WALL>(xr, k, bb, edge, par, wave, lane, w0, ry0, ry1, row_lo, row_hi, omw, nullptr);
+            if (st && p < 3) st[4 * p + 2] = wall_clock64();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int rr = w0 + r;
+                if (st_x && rr >= ry0 && rr < ry1 && (last || rim_x || rr < ry0 + T || rr >= ry1 - T))
+                    wgr_st2(dst, voff, (unsigned)(rr * nx) * 8u, xr[r]);
+            }
+            if (!last) {                                           // the last pass is published by the end of the launch
+                __syncthreads();                                   // every wave's stores are acknowledged (vmcnt 0) before the barrier
+                if (threadIdx.x == 0)
+                    __hip_atomic_store(flags + (size_t)bt * WGR_FLAG_STRIDE, base + (unsigned)p + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (st && p < 3) st[4 * p + 3] = wall_clock64();
+            }
+        }
+    };
+    if (wall) passes(TbTag<true>{});
+    else passes(TbTag<false>{});
 }
 
 }  // namespace deff

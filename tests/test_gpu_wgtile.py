@@ -178,3 +178,65 @@ def test_wgtile_1024_vs_oracle(pkg, oracle):
             s.init_linear(0.0, 1.0)
             s.sweeps(27)
             assert_field(s.get_field(), want)
+
+
+@pytest.mark.parametrize("resident", [1, 2, 0])          # 2: resident through a cooperative launch (tb_coop = 1)
+@pytest.mark.parametrize("T,R", [(8, 7), (8, 4), (4, 6), (8, 6)])
+@pytest.mark.parametrize("shape", [(600, 300), (1030, 37), (130, 70), (256, 256), (2, 64), (1001, 333), (1024, 1024)])
+def test_resident_passes_vs_oracle(pkg, oracle, shape, T, R, resident):
+    """Resident passes (k_sweep_wgres): all tiles on the chip, the passes of a batch in ONE launch, neighbours synchronised
+    through per-tile flags -- through a plain launch (1), a cooperative launch (2), and switched off (0: one launch per pass).
+    5 passes + 3 single sweeps, then 2 more passes (a second launch: epoch counters carry over), against the oracle."""
+    nx, ny = shape
+    if (nx, ny) == (1024, 1024) and (T, R) != (8, 7):
+        pytest.skip("1024^2 once, on the planner's own tile")
+    rng = np.random.default_rng(nx * 3 + ny * 5 + T + R)
+    pix = rand_mask(rng, nx, ny, 0.5)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-3)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    x0 = rng.random((ny, nx))
+    n1, n2 = 5 * T + 3, 2 * T
+    want1 = oracle.sweeps(A, b, x0, n1)
+    want2 = oracle.sweeps(A, b, want1, n2)
+    with pkg.Solver(nx, ny, kernel="matfree_tb") as s:
+        s.set_tuning("tb_T", T); s.set_tuning("tb_impl", 2); s.set_tuning("tb_R", R)
+        s.set_tuning("tb_resident", min(resident, 1)); s.set_tuning("tb_coop", 1 if resident == 2 else 0)
+        s.set_image(pix)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.set_field(x0)
+        s.sweeps(n1)
+        p = s.plan()
+        assert p["tb_impl"] == 2 and p["tb_T"] == T
+        tiles = p["tb_strips"] * p["tb_chunks_per_image"]
+        expect = bool(resident) and tiles <= 256
+        assert p["tb_resident"] == int(expect), p
+        launches, _ = s.last_launches()
+        assert launches == (1 + 3 if expect else 5 + 3)
+        assert_field(s.get_field(), want1)
+        s.sweeps(n2)
+        assert_field(s.get_field(), want2)
+
+
+def test_resident_stack_with_frozen_images(pkg, oracle):
+    """A stack of images on resident passes: tiles wait only for tiles of their own image, and a frozen image's tiles
+    take no part (solve_batch freezes each image at ITS stopping rule); per-image iteration counts, Deff and fields
+    must equal one-image-at-a-time solves on the per-pass path."""
+    nx = ny = 128
+    B = 6
+    rng = np.random.default_rng(77)
+    imgs = [rand_mask(rng, nx, ny, 0.35 + 0.05 * k) for k in range(B)]
+    res = {}
+    for resident in (1, 0):
+        with pkg.Solver(nx, ny, nimg=B, kernel="matfree_tb") as s:
+            s.set_tuning("tb_impl", 2); s.set_tuning("tb_resident", resident)
+            s.set_image(np.stack(imgs))
+            s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+            s.init_linear(0.0, 1.0)
+            r = s.solve(1e-3, 200000, check_every=500)
+            assert s.plan()["tb_resident"] == resident
+            res[resident] = (r, s.get_field())
+    ra, fa = res[1]
+    rb, fb = res[0]
+    assert [x.iters for x in ra] == [x.iters for x in rb] and len({x.iters for x in ra}) > 1
+    assert [x.deff_raw for x in ra] == [x.deff_raw for x in rb]
+    assert np.array_equal(fa, fb)
