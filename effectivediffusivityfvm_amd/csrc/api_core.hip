@@ -214,8 +214,10 @@ try {
     else if (!strcmp(key, "tb_LY")) c->tb_LY = value;
     else if (!strcmp(key, "tb_impl")) c->tb_impl = value > 2 ? 0 : value;
     else if (!strcmp(key, "tb_R")) c->tb_R = value;
-    else if (!strcmp(key, "tb_resident")) c->tb_resident = value ? 1 : 0;
-    else if (!strcmp(key, "tb_coop")) c->tb_coop = value ? 1 : 0;
+    else if (!strcmp(key, "tb_launch")) {            // 0 / 2: resident passes where possible (2: cooperative launch); 1: one launch per pass
+        c->tb_resident = value == 1 ? 0 : 1;
+        c->tb_coop = value == 2 ? 1 : 0;
+    }
     else if (!strcmp(key, "flux_reduce")) c->flux_reduce = value > 2 ? 0 : value;
     else if (!strcmp(key, "tb_NW")) c->tb_NW = value;
     else if (!strcmp(key, "dict")) c->dict_enabled = value ? 1 : 0;

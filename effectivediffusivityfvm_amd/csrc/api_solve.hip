@@ -172,7 +172,7 @@ int resident_check(deff_ctx *c)
         HIP_TRY(hipMemsetAsync(c->res_abort, 0, sizeof h, c->stream));
         c->have_field = false;
         return fail(DEFF_EHIP, "resident passes aborted: a workgroup waited more than 2 s for a neighbouring tile "
-                               "(the field is invalid; set tuning tb_resident = 0 to launch every pass separately)");
+                               "(the field is invalid; set tuning tb_launch = 1 to launch every pass separately)");
     }
     return DEFF_OK;
 }

@@ -149,11 +149,12 @@ struct deff_ctx {
     int tb_impl = 0, tb_R = 0, tb_NW = 0;
     // resident passes (kernels_wgtile.hpp, k_sweep_wgres): when every tile of the context is on the chip at once, all the
     // passes between two checks are ONE launch whose tiles keep their matrix rows and owned cells in registers and wait
-    // for their neighbours only.  tb_resident: 1 = whenever the tiles are co-resident (default), 0 = never (one launch per
-    // pass).  tb_coop: 0 = plain launch (default): the grid fits the chip by the occupancy query, resident launches of one
-    // process are chained per device (api_solve.hip) so that two of them never share the chip, and every wait is bounded;
-    // 1 = hipLaunchCooperativeKernel, which makes the runtime vouch for co-residency -- not the default because ROCm
-    // 7.2's teardown segfaults at process exit once several host threads have launched cooperatively (deff2d --devices).
+    // for their neighbours only.  Tuning key "tb_launch": 0 = resident passes whenever the tiles are co-resident, through
+    // a plain launch (default: the grid fits the chip by the occupancy query, resident launches of one process are chained
+    // per device, api_solve.hip, so that two of them never share the chip, and every wait is bounded); 1 = never (one
+    // launch per pass); 2 = resident through hipLaunchCooperativeKernel, which makes the runtime vouch for co-residency --
+    // not the default because ROCm 7.2's teardown segfaults at process exit once several host threads have launched
+    // cooperatively (deff2d --devices 0,0,0).
     int tb_resident = 1, tb_coop = 0;
     int plan_resident = 0;                       // the last plan used resident passes
     unsigned *res_flags = nullptr;               // per tile: passes completed (epoch counter)

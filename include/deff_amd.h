@@ -77,14 +77,18 @@ int deff_set_kernel(deff_ctx *ctx, int kernel);
 int deff_get_kernel(const deff_ctx *ctx, int *kernel_in_use);
 /* tuning knob; 0 restores the default.  Keys: "rows_explicit", "rows_matfree", "wg_matfree",
  * "nt_explicit", "serpentine", "tb_T" (sweeps per pass: 1,2,4,6,8), "tb_LY" (rows per chunk), "tb_wg",
- * "tb_xmajor", "tb_wall_halo", "dict" (harvest a row dictionary from explicit systems: 1 default), and
+ * "tb_xmajor", "tb_wall_halo", "dict" (harvest a row dictionary from explicit systems: 1 default),
+ * "tb_impl" (1 streaming, 2 workgroup tiles), "tb_R", "tb_launch" (workgroup tiles whose tiles all fit the chip
+ *   run every pass between two checks in ONE launch, neighbouring tiles synchronised by flags: 1 = one launch per
+ *   pass instead, 2 = through hipLaunchCooperativeKernel), "flux_reduce", and
  *   "fma" = 1: contracted arithmetic -- the reference's expressions (cuh:74-89, cuh:1957) with each
  *   product fused into the following add, as nvcc's default -fmad=true / gcc -ffp-contract=fast compile
  *   them; bit-identical to the oracle's fma build, not to the default (written-order) arithmetic.
  *   Set it before deff_init_linear(); it applies to every sweep kernel. */
 int deff_set_tuning(deff_ctx *ctx, const char *key, int value);
 /* what the last launch plan of the temporally blocked kernel chose: "tb_T", "tb_LY" (rows per chunk),
- * "tb_strips", "tb_chunks_per_image", "tb_blocks" (workgroups launched); 0 before any sweep */
+ * "tb_strips", "tb_chunks_per_image", "tb_blocks" (workgroups launched), "tb_impl", "tb_R", "tb_resident" (1: the
+ * passes of a batch run as one resident launch); 0 before any sweep */
 int deff_get_plan(deff_ctx *ctx, const char *key, int *value);
 
 /* ---- image -> phases: replaces the mask->D loops cuh:1988-2000 (2-phase),

@@ -180,12 +180,13 @@ def test_wgtile_1024_vs_oracle(pkg, oracle):
             assert_field(s.get_field(), want)
 
 
-@pytest.mark.parametrize("resident", [1, 2, 0])          # 2: resident through a cooperative launch (tb_coop = 1)
+@pytest.mark.parametrize("launch", [0, 2, 1])            # tuning key tb_launch
 @pytest.mark.parametrize("T,R", [(8, 7), (8, 4), (4, 6), (8, 6)])
 @pytest.mark.parametrize("shape", [(600, 300), (1030, 37), (130, 70), (256, 256), (2, 64), (1001, 333), (1024, 1024)])
-def test_resident_passes_vs_oracle(pkg, oracle, shape, T, R, resident):
+def test_resident_passes_vs_oracle(pkg, oracle, shape, T, R, launch):
     """Resident passes (k_sweep_wgres): all tiles on the chip, the passes of a batch in ONE launch, neighbours synchronised
-    through per-tile flags -- through a plain launch (1), a cooperative launch (2), and switched off (0: one launch per pass).
+    through per-tile flags -- through a plain launch (tb_launch = 0, the default), a cooperative launch (2), and switched off (1: one
+    launch per pass).
     5 passes + 3 single sweeps, then 2 more passes (a second launch: epoch counters carry over), against the oracle."""
     nx, ny = shape
     if (nx, ny) == (1024, 1024) and (T, R) != (8, 7):
@@ -200,7 +201,7 @@ def test_resident_passes_vs_oracle(pkg, oracle, shape, T, R, resident):
     want2 = oracle.sweeps(A, b, want1, n2)
     with pkg.Solver(nx, ny, kernel="matfree_tb") as s:
         s.set_tuning("tb_T", T); s.set_tuning("tb_impl", 2); s.set_tuning("tb_R", R)
-        s.set_tuning("tb_resident", min(resident, 1)); s.set_tuning("tb_coop", 1 if resident == 2 else 0)
+        s.set_tuning("tb_launch", launch)
         s.set_image(pix)
         s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
         s.set_field(x0)
@@ -208,7 +209,7 @@ def test_resident_passes_vs_oracle(pkg, oracle, shape, T, R, resident):
         p = s.plan()
         assert p["tb_impl"] == 2 and p["tb_T"] == T
         tiles = p["tb_strips"] * p["tb_chunks_per_image"]
-        expect = bool(resident) and tiles <= 256
+        expect = launch != 1 and tiles <= 256
         assert p["tb_resident"] == int(expect), p
         launches, _ = s.last_launches()
         assert launches == (1 + 3 if expect else 5 + 3)
@@ -228,7 +229,7 @@ def test_resident_stack_with_frozen_images(pkg, oracle):
     res = {}
     for resident in (1, 0):
         with pkg.Solver(nx, ny, nimg=B, kernel="matfree_tb") as s:
-            s.set_tuning("tb_impl", 2); s.set_tuning("tb_resident", resident)
+            s.set_tuning("tb_impl", 2); s.set_tuning("tb_launch", 0 if resident else 1)
             s.set_image(np.stack(imgs))
             s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
             s.init_linear(0.0, 1.0)

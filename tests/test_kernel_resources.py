@@ -62,6 +62,18 @@ def test_workgroup_tile_kernel_fits_two_waves_per_simd(usage):
                 assert u["LDS"] <= 64 * 1024, (name, u)
 
 
+def test_resident_kernel_fits_two_waves_per_simd(usage):
+    """k_sweep_wgres<T, R, FMA, GUARD> (the resident form of the same tiles): same budget; the few spilled registers of
+    R = 7 are the codes during the one-time lookups and six values around the pass loop's end, not in the sweeps."""
+    for R, scratch in ((4, 0), (6, 0), (7, 64)):
+        for T in (4, 8):
+            for name, u in kernels(usage, f"_ZN4deff13k_sweep_wgresILi{T}ELi{R}E").items():
+                guard = re.search(r"ELb[01]ELb1EEE", name) is not None      # zero-diffusivity variant: SGPR-heavy branches
+                assert u["Occupancy"] >= 2 and u["VGPRs"] <= 256 and u["AGPRs"] == 0, (name, u)
+                assert u["ScratchSize"] <= (max(scratch, 64) if guard else scratch), (name, u)
+                assert u["LDS"] <= 64 * 1024, (name, u)
+
+
 def test_single_sweep_kernels_are_light(usage):
     for prefix in ("_ZN4deff16k_sweep_explicitI", "_ZN4deff15k_sweep_matfreeI", "_ZN4deff14k_sweep_scalarI"):
         for name, u in kernels(usage, prefix).items():

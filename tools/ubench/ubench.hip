@@ -2,6 +2,7 @@
 // how many clocks a wave64 FP64 add / mul / fma, a DPP move and a ds_read_b64 occupy their unit.
 // Each kernel runs `iters` iterations of 8 independent chains per lane; all waves of the chip busy.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -159,6 +160,28 @@ __global__ __launch_bounds__(256) void k_level(double *out, int iters, double om
     out[blockIdx.x * blockDim.x + threadIdx.x] = vS.x + vS.y + vC.x + vN.y + (double)cw;
 }
 
+// ---- HBM streams by read / write mix (./ubench mem): what the memory system gives a kernel that reads NR 8-byte streams
+// and writes NW, 16 bytes per lane per access, grid-stride -- the ceiling a sweep kernel of the same mix can be held
+// against (the explicit sweep reads 7 and writes 1, the matrix-free one reads 1.25 and writes 1).
+template <int NR, int NW>
+__global__ __launch_bounds__(256) void k_stream(const double2 *__restrict__ in, double2 *__restrict__ out, size_t n2, size_t plane2)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
+        double2 a = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const double2 v = in[(size_t)r * plane2 + i];
+            a.x += v.x; a.y += v.y;
+        }
+        if constexpr (NW > 0) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) out[(size_t)w * plane2 + i] = a;
+        } else {
+            if (a.x == 1.2345e300) out[i] = a;                      // never: keeps the loads
+        }
+    }
+}
+
 template <class F>
 static double time_ms(F launch)
 {
@@ -175,8 +198,40 @@ static double time_ms(F launch)
     return ms;
 }
 
-int main()
+static int mem_main()
 {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const size_t n = (size_t)4096 * 4096, n2 = n / 2;
+    double2 *in, *out;
+    CHECK(hipMalloc(&in, sizeof(double) * n * 7));
+    CHECK(hipMalloc(&out, sizeof(double) * n * 2));
+    CHECK(hipMemset(in, 0, sizeof(double) * n * 7));
+    CHECK(hipMemset(out, 0, sizeof(double) * n * 2));
+    printf("%s: HBM streams over 4096^2 doubles per plane, 16 B per lane per access\n", prop.gcnArchName);
+    auto run = [&](const char *name, auto kern, int nr, int nw) {
+        for (int blocks : {2048, 4096, 8192, 16384}) {
+            double best = 1e9;
+            for (int rep = 0; rep < 5; ++rep) {
+                const double ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, in, out, n2, n2); });
+                if (ms < best) best = ms;
+            }
+            printf("  %-28s %5d blocks: %8.2f us  %7.0f GB/s\n", name, blocks, best * 1e3, (nr + nw) * 8.0 * n / (best * 1e-3) / 1e9);
+        }
+    };
+    run("read 1", k_stream<1, 0>, 1, 0);
+    run("read 7", k_stream<7, 0>, 7, 0);
+    run("read 1 write 1 (copy)", k_stream<1, 1>, 1, 1);
+    run("read 2 write 1", k_stream<2, 1>, 2, 1);
+    run("read 7 write 1 (explicit)", k_stream<7, 1>, 7, 1);
+    run("read 1 write 2", k_stream<1, 2>, 1, 2);
+    CHECK(hipFree(in)); CHECK(hipFree(out));
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1 && !strcmp(argv[1], "mem")) return mem_main();
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
