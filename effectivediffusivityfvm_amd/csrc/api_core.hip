@@ -214,6 +214,7 @@ try {
     else if (!strcmp(key, "tb_LY")) c->tb_LY = value;
     else if (!strcmp(key, "tb_impl")) c->tb_impl = value > 2 ? 0 : value;
     else if (!strcmp(key, "tb_R")) c->tb_R = value;
+    else if (!strcmp(key, "tb_debug_stall")) c->tb_debug_stall = value;
     else if (!strcmp(key, "tb_launch")) {            // 0 / 2: resident passes where possible (2: cooperative launch); 1: one launch per pass
         c->tb_resident = value == 1 ? 0 : 1;
         c->tb_coop = value == 2 ? 1 : 0;
@@ -637,6 +638,7 @@ try {
     if (!c || !x) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
     TRY(consolidate(c));
+    if (!c->have_field) return fail(DEFF_ESTATE, "no field: call deff_init_linear() or deff_set_field()");
     TRY(rows_d2h(c, x, (const double *)c->x[c->cur], (size_t)c->rows));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DEFF_OK;

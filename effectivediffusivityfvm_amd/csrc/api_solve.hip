@@ -134,6 +134,7 @@ static hipError_t launch_wgres(deff_ctx *c, const SweepPlan &pl, double *xa, dou
 {
     unsigned long long *stamps = c->tb_stamps;
     unsigned xbytes = (unsigned)(c->n * sizeof(double));
+    int stall_tile = c->tb_debug_stall - 1;
     const double *lut = c->lut;
     const uint16_t *code = c->code;
     int nx = c->nx, ny = c->mesh_ny, img_stride = c->ny, dom_lo = c->dom_lo, own_lo = pl.own_lo, own_h = pl.own_h;
@@ -148,13 +149,13 @@ static hipError_t launch_wgres(deff_ctx *c, const SweepPlan &pl, double *xa, dou
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_sweep_wgres<T, R, F, G>), dim3(pl.tblocks), dim3(WGT_WAVES * 64), 0, c->stream, lut, code, xa,
                            xb, nx, ny, img_stride, dom_lo, own_lo, own_h, cpi, ly, mask, ntx, gy, xmajor, allb, nrows, shift,
-                           omw, npass, flags, base, abort_flag, xbytes, stamps);
+                           omw, npass, flags, base, abort_flag, xbytes, stall_tile, stamps);
         e = hipPeekAtLastError();
         if (e != hipSuccess) return e;
         return resident_chain_end(c);
     }
     void *args[] = {&lut, &code, &xa, &xb, &nx, &ny, &img_stride, &dom_lo, &own_lo, &own_h, &cpi, &ly, &mask, &ntx, &gy,
-                    &xmajor, &allb, &nrows, &shift, &omw, &npass, &flags, &base, &abort_flag, &xbytes, &stamps};
+                    &xmajor, &allb, &nrows, &shift, &omw, &npass, &flags, &base, &abort_flag, &xbytes, &stall_tile, &stamps};
     return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&k_sweep_wgres<T, R, F, G>), dim3(pl.tblocks),
                                       dim3(WGT_WAVES * 64), args, 0, c->stream);
 }

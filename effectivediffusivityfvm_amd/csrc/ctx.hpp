@@ -156,6 +156,7 @@ struct deff_ctx {
     // not the default because ROCm 7.2's teardown segfaults at process exit once several host threads have launched
     // cooperatively (deff2d --devices 0,0,0).
     int tb_resident = 1, tb_coop = 0;
+    int tb_debug_stall = 0;                      // tests: tile (index + 1) that leaves a resident launch without publishing
     int plan_resident = 0;                       // the last plan used resident passes
     unsigned *res_flags = nullptr;               // per tile: passes completed (epoch counter)
     size_t res_flags_n = 0;

@@ -344,7 +344,8 @@ __global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgtile(const double
 // Forward progress: the launch is cooperative (hipLaunchCooperativeKernel refuses a grid that is not co-resident), and
 // every wait is bounded -- a lane that has polled for WGR_TIMEOUT of the 100 MHz wall clock, or that sees *abort_flag set,
 // raises *abort_flag and its workgroup returns; so does, within one poll, every workgroup waiting anywhere.  The host
-// checks the flag at its next synchronisation and fails the call (api_solve.hip).
+// checks the flag at its next synchronisation and fails the call (api_solve.hip).  (stall_tile >= 0 makes that tile
+// leave without publishing -- the tests' way to exercise this path.)
 // Same arithmetic, same tiles, same results bit for bit as npass launches of k_sweep_wgtile.
 constexpr unsigned long long WGR_TIMEOUT = 200000000ull;       // 2 s
 constexpr int WGR_FLAG_STRIDE = 64;                            // unsigneds between two tiles' flags: one 256-byte block each, so that
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgres(const double 
                                                                    int xmajor, int allb, int nrows, int shift,
                                                                    double omw, int npass, unsigned *flags,
                                                                    unsigned base, unsigned *abort_flag,
-                                                                   unsigned xbytes,
+                                                                   unsigned xbytes, int stall_tile,
                                                                    unsigned long long *__restrict__ stamps)
 {
     constexpr int NW = WGT_WAVES;
@@ -515,7 +516,13 @@ __global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgres(const double 
                     wgr_st2(dst, voff, (unsigned)(rr * nx) * 8u, xr[r]);
             }
             if (!last) {                                           // the last pass is published by the end of the launch
-                __syncthreads();                                   // every wave's stores are acknowledged (vmcnt 0) before the barrier
+                if ((int)bt == stall_tile) return;                 // test hook (tuning "tb_debug_stall"): a tile that never publishes
+                // Every wave waits until ITS rim stores are acknowledged (written through to the coherence point), then the
+                // barrier, then the flag.  The wait must be spelled out: a workgroup-scope barrier does not wait for global
+                // stores on gfx950 (hipcc emits s_waitcnt lgkmcnt(0) only) -- without it the flag can overtake the data
+                // (seen once, as a 1e-10 deviation of one Deff, with three contexts loading the memory system).
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
                 if (threadIdx.x == 0)
                     __hip_atomic_store(flags + (size_t)bt * WGR_FLAG_STRIDE, base + (unsigned)p + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (st && p < 3) st[4 * p + 3] = wall_clock64();

@@ -241,3 +241,75 @@ def test_resident_stack_with_frozen_images(pkg, oracle):
     assert [x.iters for x in ra] == [x.iters for x in rb] and len({x.iters for x in ra}) > 1
     assert [x.deff_raw for x in ra] == [x.deff_raw for x in rb]
     assert np.array_equal(fa, fb)
+
+
+def test_resident_launch_gives_up_instead_of_hanging(pkg):
+    """The failure path of resident passes: a tile that never publishes (test hook tb_debug_stall) leaves its neighbours
+    polling; after the bounded wait (2 s) one of them raises the abort flag, every workgroup returns, and the call fails
+    with a message -- no hang, no silent garbage.  The context is usable again after a new initial field."""
+    import time
+    nx = ny = 512
+    with pkg.Solver(nx, ny, kernel="matfree_tb") as s:
+        s.set_tuning("tb_impl", 2)
+        s.synth_image(7, 0)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(64)
+        assert s.plan()["tb_resident"] == 1
+        good = s.get_field()
+        s.set_tuning("tb_debug_stall", 12)
+        t0 = time.perf_counter()
+        with pytest.raises(pkg.DeffError, match="resident passes aborted"):
+            s.sweeps(64)
+        assert 1.5 < time.perf_counter() - t0 < 10.0
+        with pytest.raises(pkg.DeffError):
+            s.get_field()                                  # the field is gone
+        s.set_tuning("tb_debug_stall", 0)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(64)
+        assert np.array_equal(s.get_field(), good)
+
+
+def test_resident_passes_with_a_second_context_loading_the_gpu(pkg):
+    """Resident launches share the GPU with another context's kernels (a host thread sweeping a 4096^2 image on its own
+    stream): 3 x 80 000 sweeps of a 1024^2 image = 30 000 passes x 234 tiles of flag-synchronised halo exchange must give the
+    same field, bit for bit, as one launch per pass on a quiet GPU -- the rim stores are acknowledged before a tile's flag
+    is raised whatever else loads the memory system -- and must not run into the bounded wait."""
+    import hashlib
+    import threading
+    n, nsw = 1024, 80_000
+
+    def solve(launch):
+        with pkg.Solver(n, n, kernel="matfree_tb") as s:
+            s.set_tuning("tb_launch", launch)
+            s.synth_image(12345, 0)
+            s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            s.init_linear(0.0, 1.0)
+            s.sweeps(nsw)
+            assert s.plan()["tb_resident"] == (0 if launch == 1 else 1)
+            return hashlib.sha256(s.get_field().tobytes()).hexdigest()
+
+    ref = solve(1)
+    stop = threading.Event()
+    launches = []
+
+    def hammer():
+        with pkg.Solver(4096, 4096, kernel="matfree_tb") as h:
+            h.synth_image(1, 0)
+            h.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            h.init_linear(0.0, 1.0)
+            k = 0
+            while not stop.is_set():
+                h.sweeps(40)
+                k += 1
+            launches.append(k)
+
+    th = threading.Thread(target=hammer)
+    th.start()
+    try:
+        got = [solve(0) for _ in range(3)]
+    finally:
+        stop.set()
+        th.join()
+    assert launches and launches[0] >= 3
+    assert got == [ref] * 3
