@@ -1,6 +1,11 @@
 // ubench.hip -- instruction-rate microbenchmarks on gfx950 (diagnostics for DESIGN.md's kernel model):
 // how many clocks a wave64 FP64 add / mul / fma, a DPP move and a ds_read_b64 occupy their unit.
 // Each kernel runs `iters` iterations of 8 independent chains per lane; all waves of the chip busy.
+// Build (the box has hipcc; the binary travels with the snapshot):
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tools/ubench/ubench tools/ubench/ubench.hip
+// (-ffp-contract=off matters for k_level: contracted, a level is 14 FP64 instructions instead of 22 and costs 71-86 clocks
+// instead of 109-219; DESIGN.md quotes the uncontracted figures).   ./ubench      instruction rates
+//                                                                   ./ubench mem  HBM streams by read / write mix
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <cstdio>
