@@ -358,6 +358,11 @@ __global__ __launch_bounds__(256, (T >= 6 ? 3 : 1)) void k_sweep_matfree_tb(cons
 {
     static_assert(T >= 1 && T <= 8, "unsupported T");
     __shared__ double lut[LUT_DOUBLES];
+#ifdef TB_EXTRA_LDS
+    // occupancy experiment (tools/build_variant.sh occ3 -DTB_EXTRA_LDS=16384): LDS nobody uses, so that fewer workgroups fit a CU
+    __shared__ char occupancy_pad[TB_EXTRA_LDS];
+    if (nrows < 0) occupancy_pad[threadIdx.x] = 1;
+#endif
     load_lut(lut, lut_g, nrows);
 
     const int lane = threadIdx.x & 63;
