@@ -436,9 +436,12 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             pl->guard = c->lut_guard;
             }
         }
-        tile_grid(c, 256 * 2, pick_R(c->rows_matfree, c->n >= ((size_t)1 << 21) ? 8 : 2), pl);
-        // persistent grid: a few workgroups per CU walk the tiles (tables loaded once each)
-        const int cap = c->wg_matfree ? c->wg_matfree : 256 * 8;
+        // 4 rows per tile and up to 8 192 workgroups (measured at 4096^2: 52.0 us = 5.8 TB/s against 59-61 us for 8 rows x
+        // 2 048 persistent workgroups; 16384^2: 960-990 us = 4.9-5.0 TB/s either way -- above what a plain copy kernel gets
+        // from HBM for this read / write mix, tools/ubench mem: 4.7 TB/s)
+        tile_grid(c, 256 * 2, pick_R(c->rows_matfree, c->n >= ((size_t)1 << 21) ? 4 : 2), pl);
+        // persistent grid: workgroups walk the tiles (tables loaded once each)
+        const int cap = c->wg_matfree ? c->wg_matfree : 256 * 32;
         if (pl->blocks > cap) pl->blocks = cap;
     } else {
         TRY(explicit_from_image(c));

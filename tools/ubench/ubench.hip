@@ -203,19 +203,19 @@ static double time_ms(F launch)
     return ms;
 }
 
-static int mem_main()
+static int mem_main(int side)
 {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
-    const size_t n = (size_t)4096 * 4096, n2 = n / 2;
+    const size_t n = (size_t)side * side, n2 = n / 2;
     double2 *in, *out;
     CHECK(hipMalloc(&in, sizeof(double) * n * 7));
     CHECK(hipMalloc(&out, sizeof(double) * n * 2));
     CHECK(hipMemset(in, 0, sizeof(double) * n * 7));
     CHECK(hipMemset(out, 0, sizeof(double) * n * 2));
-    printf("%s: HBM streams over 4096^2 doubles per plane, 16 B per lane per access\n", prop.gcnArchName);
+    printf("%s: HBM streams over %d^2 doubles per plane (%.0f MB), 16 B per lane per access\n", prop.gcnArchName, side, n * 8e-6);
     auto run = [&](const char *name, auto kern, int nr, int nw) {
-        for (int blocks : {2048, 4096, 8192, 16384}) {
+        for (int blocks : {4096, 16384}) {
             double best = 1e9;
             for (int rep = 0; rep < 5; ++rep) {
                 const double ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, in, out, n2, n2); });
@@ -236,7 +236,7 @@ static int mem_main()
 
 int main(int argc, char **argv)
 {
-    if (argc > 1 && !strcmp(argv[1], "mem")) return mem_main();
+    if (argc > 1 && !strcmp(argv[1], "mem")) return mem_main(argc > 2 ? atoi(argv[2]) : 4096);
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
