@@ -447,7 +447,10 @@ __global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgres(const double 
         const int rr = w0 + r;
         const bool ok = in_x && rr >= ld_lo && rr < ld_hi;
         const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col : 0);
-        const double2 vx = ld2(xa + p);
+        // the field is read through device-coherent loads from the first pass on (see wgr_ld2): no line of it is ever
+        // brought into this XCD's L2 by a plain load that a later coherent load could find there
+        const double2 vx = wgr_ld2(wgr_rsrc(xa, xbytes), (unsigned)(ok ? col : 0) * 8u,
+                                   (unsigned)((rr >= ld_lo && rr < ld_hi ? rr : 0) * nx) * 8u);
         const unsigned vc = *reinterpret_cast<const uint32_t *>(code + p);
         xr[r] = ok ? vx : zero;
         cc[r] = ok ? vc : 0u;
