@@ -333,18 +333,22 @@ __global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgtile(const double
 // ---------------------------------------------------------------------------------------------------------------
 // Resident form: when ALL tiles of the context are on the chip at once (one tile per workgroup, every workgroup
 // resident: one 1024^2 image is 234 tiles on 256 CUs), the launch need not end after T sweeps.  A workgroup keeps its
-// tile's MATRIX ROWS in registers over `npass` passes and only re-reads the field (its neighbours have changed the
-// halo), so a pass costs neither a launch gap (~1.7 us), nor the dictionary fetch, nor the 70 lookups per lane of its
-// first sweep.  Between passes a tile waits for its (up to 8) neighbours only -- no grid-wide barrier:
-//   pass p reads buffer p&1 and writes the other one; after its stores a workgroup releases them at agent scope and
-//   publishes flags[tile] = base + p + 1; before re-reading the field for pass p >= 1 it waits until every
-//   neighbour's flag has reached base + p, then acquires.  (Write-after-read is covered by the same flags: a tile
-//   overwrites buffer p&1 at the end of pass p + 1, which it only starts once its neighbours have finished pass p, i.e.
-//   are done reading that buffer.)  Pass 0 needs no wait: the launch boundary orders it after everything before.
-// Forward progress: the launch is cooperative (hipLaunchCooperativeKernel refuses a grid that is not co-resident), and
-// every wait is bounded -- a lane that has polled for WGR_TIMEOUT of the 100 MHz wall clock, or that sees *abort_flag set,
-// raises *abort_flag and its workgroup returns; so does, within one poll, every workgroup waiting anywhere.  The host
-// checks the flag at its next synchronisation and fails the call (api_solve.hip).  (stall_tile >= 0 makes that tile
+// tile's MATRIX ROWS and its OWNED CELLS in registers over `npass` passes and exchanges only the halo with its (up to 8)
+// neighbours, so a pass costs neither a launch gap (~1.7 us), nor the dictionary fetch, nor the 70 lookups per lane of
+// its first sweep, nor a re-read of the tile.  No grid-wide barrier; per pass p (reads buffer p&1, writes the other one):
+//   - after its T sweeps a tile stores the RIM of its owned cells (the T outermost rows / HW outermost columns: all a
+//     neighbour ever reads; the last pass of a launch stores every owned cell), waits until those stores are
+//     acknowledged, and publishes flags[tile] = base + p + 1;
+//   - before pass p >= 1 it polls until each neighbour's flag has reached base + p and then reads its halo cells.
+//   Write-after-read is covered by the same flags: a tile overwrites buffer p&1 at the end of pass p + 1, which it only
+//   starts once its neighbours have finished pass p, i.e. are done reading that buffer.  Pass 0 needs no wait: the launch
+//   boundary orders it after everything before.  `base` grows by npass from launch to launch, so stale flags are always
+//   smaller than anything waited for.
+// Forward progress: the host launches at most as many workgroups as the occupancy query says are co-resident and never
+// two resident kernels of one process on one device at a time (api_solve.hip; or hipLaunchCooperativeKernel, tuning
+// tb_launch = 2), and every wait is bounded -- a lane that has polled for WGR_TIMEOUT of the 100 MHz wall clock, or that
+// sees *abort_flag set, raises *abort_flag and its workgroup returns; so does, within one poll, every workgroup waiting
+// anywhere.  The host checks the flag at its next synchronisation and fails the call.  (stall_tile >= 0 makes that tile
 // leave without publishing -- the tests' way to exercise this path.)
 // Same arithmetic, same tiles, same results bit for bit as npass launches of k_sweep_wgtile.
 constexpr unsigned long long WGR_TIMEOUT = 200000000ull;       // 2 s
@@ -427,8 +431,8 @@ __global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgres(const double 
     const bool st_x = in_x && (col >= out_lo) && (col < out_hi);
     const bool wall = allb || tx == 0 || tx == ntx - 1;
 
-    // diagnostics (tools/wgt_stamps.py --resident): per tile 12 clocks = entry, then for passes 0..2 {halo rows in, swept,
-    // stored and released}, pass 0's "waited" slot holding the end of the lookups
+    // diagnostics (tools/wgr_stamps.py): per tile 12 clocks = entry, then for passes 0..2 {neighbours seen, halo in, swept,
+    // rim stored and flag raised}; pass 0 has nobody to wait for (slot 0 = entry) and the last pass raises no flag
     unsigned long long *st = (stamps && threadIdx.x == 0) ? stamps + (size_t)bt * 12 : nullptr;
     if (st) st[0] = wall_clock64();
     // the neighbour this lane polls between passes (lanes 0..7 of wave 0; -1: none -- a wall, or another image)
