@@ -84,6 +84,37 @@ static int wgt_resident_blocks(const deff_ctx *c, int T, int R, bool fma, bool g
     return DEFF_OK;
 }
 
+// tall resident tiles (kernels_wgtile.hpp: 16 waves, matrix rows looked up in every sweep): T = 8, R in WGL_ROWS
+#define WGL_DISPATCH(R_, F_, G_, CALL)                                                          \
+    do {                                                                                       \
+        if ((R_) == 6) { WGT_DISPATCH_FG(8, 6, F_, G_, CALL) }                                  \
+        else if ((R_) == 8) { WGT_DISPATCH_FG(8, 8, F_, G_, CALL) }                             \
+        else if ((R_) == 10) { WGT_DISPATCH_FG(8, 10, F_, G_, CALL) }                           \
+        else if ((R_) == 12) { WGT_DISPATCH_FG(8, 12, F_, G_, CALL) }                           \
+        else { WGT_DISPATCH_FG(8, 14, F_, G_, CALL) }                                           \
+    } while (0)
+// (R = 16 -- 256-row tiles, images up to ~2600^2 -- spills inside the sweep loop: 9.9 us per sweep, slower than streaming)
+static const int WGL_ROWS[] = {6, 8, 10, 12, 14};
+static bool wgl_has_R(int R) { for (int r : WGL_ROWS) if (r == R) return true; return false; }
+
+template <int T, int R, bool F, bool G>
+static int wgl_occ(int *per_cu)
+{
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_sweep_wgres<T, R, F, G, true>, WGL_WAVES * 64, 0));
+    return DEFF_OK;
+}
+
+static int wgl_resident_blocks(const deff_ctx *c, int R, bool fma, bool guard, int *resident)
+{
+    int per_cu = 0, cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+#define OCC_CALL(T_, R_, C_, G_) TRY((wgl_occ<T_, R_, C_, G_>(&per_cu)))
+    WGL_DISPATCH(R, fma, guard, OCC_CALL);
+#undef OCC_CALL
+    *resident = per_cu * cus;
+    return DEFF_OK;
+}
+
 template <int T, int R, bool F, bool G>
 static int wgr_occ(int *per_cu)
 {
@@ -129,9 +160,10 @@ static hipError_t resident_chain_end(const deff_ctx *c)
     return hipEventRecord(g_res_ev[d], c->stream);
 }
 
-template <int T, int R, bool F, bool G>
+template <int T, int R, bool F, bool G, bool TALL = false>
 static hipError_t launch_wgres(deff_ctx *c, const SweepPlan &pl, double *xa, double *xb, int npass, unsigned base)
 {
+    constexpr int THREADS = (TALL ? WGL_WAVES : WGT_WAVES) * 64;
     unsigned long long *stamps = c->tb_stamps;
     unsigned xbytes = (unsigned)(c->n * sizeof(double));
     int stall_tile = c->tb_debug_stall - 1;
@@ -147,7 +179,7 @@ static hipError_t launch_wgres(deff_ctx *c, const SweepPlan &pl, double *xa, dou
         std::lock_guard<std::mutex> lock(g_res_mu);
         hipError_t e = resident_chain_begin(c);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_sweep_wgres<T, R, F, G>), dim3(pl.tblocks), dim3(WGT_WAVES * 64), 0, c->stream, lut, code, xa,
+        hipLaunchKernelGGL((k_sweep_wgres<T, R, F, G, TALL>), dim3(pl.tblocks), dim3(THREADS), 0, c->stream, lut, code, xa,
                            xb, nx, ny, img_stride, dom_lo, own_lo, own_h, cpi, ly, mask, ntx, gy, xmajor, allb, nrows, shift,
                            omw, npass, flags, base, abort_flag, xbytes, stall_tile, stamps);
         e = hipPeekAtLastError();
@@ -156,8 +188,8 @@ static hipError_t launch_wgres(deff_ctx *c, const SweepPlan &pl, double *xa, dou
     }
     void *args[] = {&lut, &code, &xa, &xb, &nx, &ny, &img_stride, &dom_lo, &own_lo, &own_h, &cpi, &ly, &mask, &ntx, &gy,
                     &xmajor, &allb, &nrows, &shift, &omw, &npass, &flags, &base, &abort_flag, &xbytes, &stall_tile, &stamps};
-    return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&k_sweep_wgres<T, R, F, G>), dim3(pl.tblocks),
-                                      dim3(WGT_WAVES * 64), args, 0, c->stream);
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&k_sweep_wgres<T, R, F, G, TALL>), dim3(pl.tblocks),
+                                      dim3(THREADS), args, 0, c->stream);
 }
 
 // Did a resident launch give up?  Reads the flag (one 4-byte copy + a stream synchronisation) only when such a launch was
@@ -328,7 +360,25 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
             pl->ntx = use_b ? ntx_b : ntx_a;
             // Form of the pass.  Workgroup tiles exist for T = 4 and 8; slabs' T = 1 remainder passes and the other
             // T stay on the streaming kernel.
-            const int want_impl = c->tb_impl ? c->tb_impl : default_tb_impl(c);
+            int want_impl = c->tb_impl ? c->tb_impl : default_tb_impl(c);
+            // Tall resident tiles (16 waves x R rows, kernels_wgtile.hpp): the smallest R in WGL_ROWS whose tiles all fit
+            // the chip, or 0.  They only exist resident, for T = 8, on whole contexts.
+            int tall_R = 0;
+            if (T == 8 && !pl->T_override && c->tb_resident && !c->slab && pl->band_h <= 0 && c->tb_NW != WGT_WAVES &&
+                (c->tb_NW == WGL_WAVES || (c->tb_R == 0 && c->tb_LY == 0)) &&      // not when the caller shapes the 8-wave tiles
+                c->n * sizeof(double) < ((size_t)1 << 31)) {
+                for (int R : WGL_ROWS) {
+                    if (c->tb_NW == WGL_WAVES && wgl_has_R(c->tb_R) && R != c->tb_R) continue;
+                    const int lymax = wgl_rows_owned(T, R);
+                    const long tiles = (long)pl->ntx * ((own_h + lymax - 1) / lymax) * c->nimg;
+                    int res = 0;
+                    TRY(wgl_resident_blocks(c, R, pl->fma, c->lut_guard, &res));
+                    if (((tiles + 7) / 8) * 8 <= res) { tall_R = R; break; }
+                }
+            }
+            // a context just above the 4 Mi cells where the streaming form takes over still runs faster on tall tiles
+            // when they fit (2048^2: 228 tiles of 192 rows)
+            if (!c->tb_impl && want_impl == 1 && tall_R) want_impl = 2;
             if (want_impl == 2 && (T == 4 || T == 8) && !pl->T_override) {
                 pl->impl = 2;
                 int resident = c->tb_wg;
@@ -386,6 +436,31 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
                             HIP_TRY(hipMemsetAsync(c->res_abort, 0, sizeof(unsigned), c->stream));
                         }
                     }
+                }
+                if (tall_R && (!pl->resident || c->tb_NW == WGL_WAVES)) {
+                    pl->R = tall_R;
+                    pl->NW = WGL_WAVES;
+                    const int lymaxL = wgl_rows_owned(T, tall_R);
+                    int cpiL = (own_h + lymaxL - 1) / lymaxL;
+                    pl->LY = (own_h + cpiL - 1) / cpiL;
+                    pl->tcpi = (own_h + pl->LY - 1) / pl->LY;
+                    pl->tgy = pl->tcpi * c->nimg;
+                    const long tilesL = (long)pl->ntx * pl->tgy;
+                    pl->tgx = (int)tilesL;
+                    pl->tblocks = (int)(((tilesL + 7) / 8) * 8);
+                    pl->resident = true;
+                    if (c->res_flags_n < (size_t)tilesL) {
+                        if (c->res_flags) { HIP_TRY(hipFree(c->res_flags)); c->res_flags = nullptr; }
+                        TRY(dev_alloc(&c->res_flags, (size_t)tilesL * WGR_FLAG_STRIDE));
+                        HIP_TRY(hipMemsetAsync(c->res_flags, 0, sizeof(unsigned) * tilesL * WGR_FLAG_STRIDE, c->stream));
+                        c->res_flags_n = (size_t)tilesL;
+                    }
+                    if (!c->res_abort) {
+                        TRY(dev_alloc(&c->res_abort, 1));
+                        HIP_TRY(hipMemsetAsync(c->res_abort, 0, sizeof(unsigned), c->stream));
+                    }
+                    if (c->coop_launch < 0)
+                        HIP_TRY(hipDeviceGetAttribute(&c->coop_launch, hipDeviceAttributeCooperativeLaunch, c->device));
                 }
                 if (pl->band_h <= 0) {
                     c->plan_T = pl->T; c->plan_LY = pl->LY; c->plan_ntx = pl->ntx; c->plan_cpi = pl->tcpi;
@@ -529,6 +604,7 @@ void launch_tb_pass(deff_ctx *c, const SweepPlan &pl)
     double *xout = c->x[c->cur ^ 1];
     const int flip = c->serpentine ? c->cur : 0;
     const uint8_t *mask = c->masked ? c->active : nullptr;
+    if (pl.impl == 2 && pl.NW == WGL_WAVES) return;    // tall tiles only launch resident (enqueue_sweeps); reached only after a failed launch
     if (pl.impl == 2) {
 #define LAUNCH_WGT(T_, R_, C_, G_)                                                                             \
     hipLaunchKernelGGL((k_sweep_wgtile<T_, R_, C_, G_>), dim3(pl.tblocks), dim3(WGT_WAVES * 64), 0, c->stream, c->lut, \
@@ -552,15 +628,21 @@ void launch_tb_pass(deff_ctx *c, const SweepPlan &pl)
 // n sweeps: as many T-sweep passes as fit, the rest one at a time.
 void enqueue_sweeps(deff_ctx *c, const SweepPlan &pl, int64_t n)
 {
-    if (pl.kernel == DEFF_KERNEL_MATFREE_TB && pl.impl == 2 && pl.resident && n >= 2 * pl.T) {
+    if (pl.kernel == DEFF_KERNEL_MATFREE_TB && pl.impl == 2 && pl.resident && n >= (pl.NW == WGL_WAVES ? 1 : 2) * pl.T) {
         // all whole passes in launches of up to 4 096 passes (tens of milliseconds each)
         int64_t np = n / pl.T;
         while (np > 0) {
             const int chunk = (int)(np < 4096 ? np : 4096);
             hipError_t e = hipSuccess;
+            if (pl.NW == WGL_WAVES) {
+#define LAUNCH_WGL(T_, R_, C_, G_) e = launch_wgres<T_, R_, C_, G_, true>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch)
+                WGL_DISPATCH(pl.R, pl.fma, pl.guard, LAUNCH_WGL);
+#undef LAUNCH_WGL
+            } else {
 #define LAUNCH_WGR(T_, R_, C_, G_) e = launch_wgres<T_, R_, C_, G_>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch)
-            WGT_DISPATCH(pl.T, pl.R, pl.fma, pl.guard, LAUNCH_WGR);
+                WGT_DISPATCH(pl.T, pl.R, pl.fma, pl.guard, LAUNCH_WGR);
 #undef LAUNCH_WGR
+            }
             if (e != hipSuccess) break;                            // left in hipGetLastError() for the caller
             c->res_epoch += (unsigned)chunk;
             c->res_pending = true;

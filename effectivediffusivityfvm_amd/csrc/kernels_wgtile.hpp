@@ -331,6 +331,100 @@ __global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgtile(const double
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Tall tiles (resident form only): 16 waves per workgroup (4 per SIMD, 128 VGPRs), R rows per wave of which only the
+// FIELD lives in registers (4 VGPRs per tile row instead of 24); the rows' 16-bit codes sit in LDS (256 B per tile row)
+// and the matrix rows are looked up in the dictionary in every sweep, like the streaming kernel does (tb_pair) -- four
+// waves per SIMD hide those lookups.  A tile is 16R rows x 128
+// columns (R = 12: 192 rows, 176 x 112 owned = 80 % of the cells it sweeps; the 8-wave tiles own 62 %), which is what puts
+// images between 1024^2 and ~2300^2 -- too many 56-row tiles for residency, too few cells for tall streaming chunks --
+// on the chip all at once.  Same mailbox, one barrier per sweep, rows updated in place top to bottom.
+constexpr int WGL_WAVES = 16;
+constexpr int wgl_rows_owned(int T, int R) { return WGL_WAVES * R - 2 * T; }
+
+template <int T, int R, bool FMA, bool GUARD, bool WALL>
+__device__ __forceinline__ void wgl_sweeps(double2 (&xr)[R], const unsigned *codes, const double *lut,
+                                           double2 (&edge)[2][WGL_WAVES][2][64], int &par, const int wave, const int lane,
+                                           const int w0, const int ry0, const int ry1, const int row_lo, const int row_hi,
+                                           const double omw)
+{
+    constexpr int NW = WGL_WAVES;
+    const double2 zero = make_double2(0.0, 0.0);
+    const double *lut_t = lut;
+    // One row: lookups + arithmetic, FINISHED before the next row starts.  The empty asm pins the result where it is
+    // computed: without it hipcc sinks the arithmetic of every row below the sweep's barrier (nothing above needs the
+    // results) while the lookups stay above it -- all 10R coefficients live at once, 1 KiB of scratch per lane at R = 12
+    // and 50 us per sweep.
+    auto row = [&](const int r, const double2 n_, const double2 c_, const double2 s_) __attribute__((always_inline)) {
+        const double xw0 = from_lane_below(c_.y), xe1 = from_lane_above(c_.x);
+        const unsigned cw = codes[r * 64];                     // this lane's two 16-bit codes of tile row r (LDS)
+        double2 o;
+        if constexpr (R >= 13) {
+            // the two cells one after the other: half the coefficients live at a time -- what lets R = 14 stay out of
+            // scratch in this loop (2304^2: 966 G against 563 with the two cells stage-wise; at R = 8 stage-wise is 8 % faster)
+            o.x = tb_cell<GUARD, WALL, FMA>(lut_t, cw & 0xFFFFu, c_.x, xw0, c_.y, s_.x, n_.x, omw);
+            asm volatile("" : "+v"(o.x));
+            o.y = tb_cell<GUARD, WALL, FMA>(lut_t, cw >> 16, c_.y, c_.x, xe1, s_.y, n_.y, omw);
+            asm volatile("" : "+v"(o.y));
+        } else {
+            o = tb_pair<GUARD, WALL, FMA>(lut_t, cw & 0xFFFFu, cw >> 16, c_, xw0, xe1, s_, n_, omw);
+            asm volatile("" : "+v"(o.x), "+v"(o.y));
+        }
+        return o;
+    };
+#pragma unroll 1
+    for (int t = 1; t <= T; ++t) {
+        // The lookups of a row do not change from sweep to sweep, and hipcc knows: left alone it hoists all 10R of them out
+        // of this loop, i.e. rebuilds the 8-wave form's registers (20 per tile row) inside a 128-VGPR budget -- 1 KiB of
+        // scratch per lane at R = 12.  An offset the compiler cannot see through (always 0) ties them to their sweep.
+        unsigned salt = 0;
+        asm volatile("" : "+s"(salt));
+        lut_t = reinterpret_cast<const double *>(reinterpret_cast<const char *>(lut) + salt);
+        const int need_lo = max(ry0 - (T - t), row_lo), need_hi = min(ry1 + (T - t), row_hi);
+        edge[par][wave][0][lane] = xr[0];
+        edge[par][wave][1][lane] = xr[R - 1];
+        const bool any = w0 + R > need_lo && w0 < need_hi;
+        const bool full = w0 >= need_lo && w0 + R <= need_hi;
+        if (full) {
+            const double2 old1 = xr[1], oldp = xr[R - 2];
+            double2 prev = xr[0];
+#pragma unroll
+            for (int r = 1; r <= R - 2; ++r) {
+                const double2 cur = xr[r];
+                xr[r] = row(r, prev, cur, xr[r + 1]);
+                prev = cur;
+                __builtin_amdgcn_sched_barrier(0);             // keep the next rows' lookups where they are (see tb_strip)
+            }
+            __syncthreads();
+            const double2 top = (wave > 0) ? edge[par][wave - 1][1][lane] : zero;
+            const double2 bot = (wave < NW - 1) ? edge[par][wave + 1][0][lane] : zero;
+            xr[0] = row(0, top, xr[0], old1);
+            __builtin_amdgcn_sched_barrier(0);
+            xr[R - 1] = row(R - 1, oldp, xr[R - 1], bot);
+        } else if (any) {
+            const double2 old1 = xr[1], oldp = xr[R - 2];
+            double2 prev = xr[0];
+#pragma unroll
+            for (int r = 1; r <= R - 2; ++r) {
+                const double2 cur = xr[r];
+                const int rr = w0 + r;
+                if (rr >= need_lo && rr < need_hi) xr[r] = row(r, prev, cur, xr[r + 1]);
+                prev = cur;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            const double2 top = (wave > 0) ? edge[par][wave - 1][1][lane] : zero;
+            const double2 bot = (wave < NW - 1) ? edge[par][wave + 1][0][lane] : zero;
+            if (w0 >= need_lo && w0 < need_hi) xr[0] = row(0, top, xr[0], old1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (w0 + R - 1 >= need_lo && w0 + R - 1 < need_hi) xr[R - 1] = row(R - 1, oldp, xr[R - 1], bot);
+        } else {
+            __syncthreads();
+        }
+        par ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Resident form: when ALL tiles of the context are on the chip at once (one tile per workgroup, every workgroup
 // resident: one 1024^2 image is 234 tiles on 256 CUs), the launch need not end after T sweeps.  A workgroup keeps its
 // tile's MATRIX ROWS and its OWNED CELLS in registers over `npass` passes and exchanges only the halo with its (up to 8)
@@ -382,8 +476,10 @@ __device__ __forceinline__ void wgr_st2(__amdgpu_buffer_rsrc_t r, unsigned voff,
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, WGR_SC1);
 }
 
-template <int T, int R, bool FMA, bool GUARD>
-__global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgres(const double *__restrict__ lut_g,
+// TALL = the 16-wave form above (matrix rows looked up in every sweep); otherwise the 8-wave form with the matrix rows in
+// registers.  The exchange protocol is the same code for both.
+template <int T, int R, bool FMA, bool GUARD, bool TALL = false>
+__global__ __launch_bounds__((TALL ? WGL_WAVES : WGT_WAVES) * 64, (TALL ? 4 : 2)) void k_sweep_wgres(const double *__restrict__ lut_g,
                                                                    const uint16_t *__restrict__ code, double *xa,
                                                                    double *xb, int nx, int ny, int img_stride,
                                                                    int dom_lo, int own_lo, int own_h, int cpi, int ly,
@@ -394,14 +490,15 @@ __global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgres(const double 
                                                                    unsigned xbytes, int stall_tile,
                                                                    unsigned long long *__restrict__ stamps)
 {
-    constexpr int NW = WGT_WAVES;
+    constexpr int NW = TALL ? WGL_WAVES : WGT_WAVES;
     static_assert(T >= 1 && T <= 8 && R >= 4, "unsupported tile");
-    static_assert(wgt_rows_owned(T, R) >= 1, "tile owns no row");
+    static_assert(NW * R - 2 * T >= 1, "tile owns no row");
     constexpr int HW = (T + 1) & ~1;
     constexpr int WOUT = TB_COLS - 2 * HW;
 
     __shared__ double lut[LUT_DOUBLES];
     __shared__ double2 edge[2][NW][2][64];
+    __shared__ unsigned codes_lds[TALL ? NW * R * 64 : 1];         // tall tiles: the codes of every tile row
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -458,18 +555,22 @@ __global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgres(const double 
         const unsigned vc = *reinterpret_cast<const uint32_t *>(code + p);
         xr[r] = ok ? vx : zero;
         cc[r] = ok ? vc : 0u;
+        if constexpr (TALL) codes_lds[(wave * R + r) * 64 + lane] = cc[r];      // read back by the same lane only
     }
     load_lut<NW * 64>(lut, lut_g, nrows);
 
     auto passes = [&](auto wall_tag) __attribute__((always_inline)) {
         constexpr bool WALL = decltype(wall_tag)::value;
-        WgtCoef k[R];
-        double2 bb[WALL ? R : 1];
+        // the 8-wave form looks its matrix rows up ONCE per launch
+        WgtCoef k[TALL ? 1 : R];
+        double2 bb[(WALL && !TALL) ? R : 1];
+        if constexpr (!TALL) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            double2 b_;
-            wgt_lookup<WALL>(lut, cc[r], k[r], b_);
-            if constexpr (WALL) bb[r] = b_;
+            for (int r = 0; r < R; ++r) {
+                double2 b_;
+                wgt_lookup<WALL>(lut, cc[r], k[r], b_);
+                if constexpr (WALL) bb[r] = b_;
+            }
         }
         const __amdgpu_buffer_rsrc_t ra = wgr_rsrc(xa, xbytes), rb = wgr_rsrc(xb, xbytes);
         // what a tile exchanges with its neighbours: its halo (read) and the rim of its owned cells (written) -- the owned
@@ -514,7 +615,8 @@ __global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgres(const double 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 st[4 * p + 1] = wall_clock64();
             }
-            wgt_sweeps<T, R, FMA, GUARD, WALL>(xr, k, bb, edge, par, wave, lane, w0, ry0, ry1, row_lo, row_hi, omw, nullptr);
+            if constexpr (TALL) wgl_sweeps<T, R, FMA, GUARD, WALL>(xr, codes_lds + wave * R * 64 + lane, lut, edge, par, wave, lane, w0, ry0, ry1, row_lo, row_hi, omw);
+            else wgt_sweeps<T, R, FMA, GUARD, WALL>(xr, k, bb, edge, par, wave, lane, w0, ry0, ry1, row_lo, row_hi, omw, nullptr);
             if (st && p < 3) st[4 * p + 2] = wall_clock64();
 #pragma unroll
             for (int r = 0; r < R; ++r) {

@@ -313,3 +313,154 @@ def test_resident_passes_with_a_second_context_loading_the_gpu(pkg):
         th.join()
     assert launches and launches[0] >= 3
     assert got == [ref] * 3
+
+
+# ---- tall resident tiles: 16 waves x R rows, field in registers, codes in LDS, matrix rows looked up in every sweep ----
+
+TALL_SHAPES = [(300, 200), (1030, 137), (600, 700), (250, 333), (2, 164), (97, 241), (1281, 410), (122, 9)]
+
+
+@pytest.mark.parametrize("R", [6, 8, 10, 12, 14])
+@pytest.mark.parametrize("shape", TALL_SHAPES)
+def test_tall_tiles_vs_oracle(pkg, oracle, shape, R):
+    """k_sweep_wgres<.., TALL>: every R, ragged strips and row tiles, images shorter than one tile, one-cell-wide
+    columns; 5 passes + 3 single sweeps, then 2 more passes in a second launch."""
+    nx, ny = shape
+    rng = np.random.default_rng(nx * 11 + ny * 3 + R)
+    pix = rand_mask(rng, nx, ny, 0.5)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-3)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    x0 = rng.random((ny, nx))
+    want1 = oracle.sweeps(A, b, x0, 43)
+    want2 = oracle.sweeps(A, b, want1, 16)
+    with pkg.Solver(nx, ny, kernel="matfree_tb") as s:
+        s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 16); s.set_tuning("tb_R", R)
+        s.set_tuning("tb_wall_halo", (nx + ny + R) % 3)
+        s.set_image(pix)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.set_field(x0)
+        s.sweeps(43)
+        p = s.plan()
+        assert (p["tb_impl"], p["tb_NW"], p["tb_R"], p["tb_T"], p["tb_resident"]) == (2, 16, R, 8, 1), p
+        assert 1 <= p["tb_LY"] <= 16 * R - 16 and p["tb_LY"] * p["tb_chunks_per_image"] >= ny
+        launches, _ = s.last_launches()
+        assert launches == 1 + 3
+        assert_field(s.get_field(), want1)
+        s.sweeps(16)
+        assert_field(s.get_field(), want2)
+
+
+@pytest.mark.parametrize("R", [6, 12, 14])
+def test_tall_tiles_omega_one_boundary_values_fma_and_launch_modes(pkg, oracle, R):
+    nx, ny = 300, 450
+    rng = np.random.default_rng(R)
+    pix = rand_mask(rng, nx, ny, 0.45)
+    D = oracle.fill_D_2phase(pix, 2.0, 0.3)
+    A, b = oracle.discretize(D, 2.0, -1.0)
+    x0 = rng.random((ny, nx))
+    for omega, kern in ((1.0, 1), (2.0 / 3.0, 0)):
+        for flavour, fma in ((None, 0), ("fma", 1)):
+            want = oracle.sweeps(A, b, x0, 25, kernel=kern, omega=omega, flavour=flavour)
+            for launch in (0, 2):
+                with pkg.Solver(nx, ny, kernel="matfree_tb") as s:
+                    s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 16); s.set_tuning("tb_R", R); s.set_tuning("fma", fma)
+                    s.set_tuning("tb_launch", launch)
+                    s.set_image(pix)
+                    s.assemble_2phase(0.3, 2.0, 2.0, -1.0)
+                    s.set_field(x0)
+                    s.sweeps(25, omega)
+                    assert s.plan()["tb_NW"] == 16
+                    assert np.array_equal(s.get_field(), want)
+    # one launch per pass requested: tall tiles (which only exist resident) are not planned
+    with pkg.Solver(nx, ny, kernel="matfree_tb") as s:
+        s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 16); s.set_tuning("tb_R", R); s.set_tuning("tb_launch", 1)
+        s.set_image(pix)
+        s.assemble_2phase(0.3, 2.0, 2.0, -1.0)
+        s.set_field(x0)
+        s.sweeps(25)
+        p = s.plan()
+        assert p["tb_NW"] == 8 and p["tb_resident"] == 0
+        assert np.array_equal(s.get_field(), oracle.sweeps(A, b, x0, 25))
+
+
+def test_tall_tiles_zero_diffusivity_guard_and_three_phase(pkg, oracle, img00000):
+    """The guarded instantiation (Ds = 0: -0.0 links, NaN cells) and a harvested dictionary (3 phases) on tall tiles."""
+    pix = np.tile(img00000, (3, 2))                              # 256 x 384: several row tiles at R = 6
+    ny, nx = pix.shape
+    D = oracle.fill_D_2phase(pix, 1.0, 0.0)
+    with np.errstate(all="ignore"):
+        A, b = oracle.discretize(D, 0.0, 1.0)
+        want = oracle.sweeps(A, b, oracle.linear_guess(nx, ny, 0.0, 1.0), 19)
+    with pkg.Solver(nx, ny, kernel="matfree_tb") as s:
+        s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 16); s.set_tuning("tb_R", 6)
+        s.set_image(pix)
+        s.assemble_2phase(0.0, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(19)
+        assert s.plan()["tb_NW"] == 16
+        assert_field(s.get_field(), want)
+    grid, _ = oracle.floodfill((pix > 200).astype(np.uint32))
+    D3 = oracle.fill_D_3phase(pix, 1.0, 0.0, 1237500.0)
+    with np.errstate(all="ignore"):
+        A3, b3 = oracle.discretize(D3, 0.0, 1.0, grid=grid)
+        want3 = oracle.sweeps(A3, b3, oracle.linear_guess(nx, ny, 0.0, 1.0), 21)
+    with pkg.Solver(nx, ny) as s:
+        s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 16); s.set_tuning("tb_R", 8)
+        s.set_image(pix)
+        s.assemble_3phase(0.0, 1.0, 1237500.0, 0.0, 1.0, grid)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(21)
+        assert s.kernel_in_use() == "matfree_tb" and s.plan()["tb_NW"] == 16
+        assert_field(s.get_field(), want3)
+
+
+def test_tall_tiles_stack_with_frozen_images(pkg, oracle):
+    """A stack on tall tiles: images stop at different checks (their tiles then leave the launch at once)."""
+    nx, ny, B = 130, 170, 5
+    rng = np.random.default_rng(99)
+    pixs = [rand_mask(rng, nx, ny, 0.35 + 0.1 * k) for k in range(B)]
+    with pkg.Solver(nx, ny, nimg=B, kernel="matfree_tb") as s:
+        s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 16); s.set_tuning("tb_R", 6)
+        s.set_image(np.stack(pixs))
+        s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        res = s.solve(1e-3, 6000, check_every=200)
+        got = s.get_field()
+        assert s.plan()["tb_NW"] == 16 and s.plan()["tb_resident"] == 1
+    iters = set()
+    for k in range(B):
+        D = oracle.fill_D_2phase(pixs[k], 1.0, 1e-2)
+        A, b = oracle.discretize(D, 0.0, 1.0)
+        it, deff, conv, x, _, _ = oracle.jacobi(A, b, oracle.linear_guess(nx, ny, 0.0, 1.0), D, 0.0, 1.0, 1e-3, 6000,
+                                                check_every=200)
+        assert (res[k].iters, res[k].deff_raw, res[k].conv) == (it, deff, conv)
+        assert_field(got[k * ny:(k + 1) * ny], x)
+        iters.add(it)
+    assert len(iters) > 1
+
+
+def test_2048_default_plan_is_tall_and_matches_the_oracle(pkg, oracle):
+    """2048^2 (4 Mi cells, where the streaming form used to take over): the planner's own choice -- 228 tiles of 192 rows --
+    against the oracle, 27 sweeps, wall fluxes and Deff too; and what it replaces gives the same bits."""
+    n = 2048
+    pix = oracle.synth_mask(n, n, 12345, 0)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-3)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    want = oracle.sweeps(A, b, oracle.linear_guess(n, n, 0.0, 1.0), 27)
+    dor, MFLo, MFRo = oracle.flux_deff(want, D, 0.0, 1.0)
+    del A, b
+    for nw in (0, 8):
+        with pkg.Solver(n, n) as s:
+            s.set_tuning("tb_NW", nw)
+            s.synth_image(12345, 0)
+            s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            s.init_linear(0.0, 1.0)
+            s.sweeps(27)
+            p = s.plan()
+            if nw == 0:
+                assert (p["tb_impl"], p["tb_NW"], p["tb_R"], p["tb_resident"]) == (2, 16, 12, 1), p
+            else:
+                assert p["tb_impl"] == 1
+            assert_field(s.get_field(), want)
+            d, MFL, MFR = s.flux()
+            assert d == dor and np.array_equal(MFL, MFLo) and np.array_equal(MFR, MFRo)

@@ -68,10 +68,32 @@ def test_resident_kernel_fits_two_waves_per_simd(usage):
     for R, scratch in ((4, 0), (6, 0), (7, 64)):
         for T in (4, 8):
             for name, u in kernels(usage, f"_ZN4deff13k_sweep_wgresILi{T}ELi{R}E").items():
-                guard = re.search(r"ELb[01]ELb1EEE", name) is not None      # zero-diffusivity variant: SGPR-heavy branches
+                m = re.search(r"ELb[01]ELb([01])ELb([01])EEE", name)           # <.., FMA, GUARD, TALL>
+                if m.group(2) == "1":
+                    continue                                         # the tall form, checked below
+                guard = m.group(1) == "1"                            # zero-diffusivity variant: SGPR-heavy branches
                 assert u["Occupancy"] >= 2 and u["VGPRs"] <= 256 and u["AGPRs"] == 0, (name, u)
                 assert u["ScratchSize"] <= (max(scratch, 64) if guard else scratch), (name, u)
                 assert u["LDS"] <= 64 * 1024, (name, u)
+
+
+def test_tall_resident_kernel_fits_four_waves_per_simd(usage):
+    """k_sweep_wgres<8, R, FMA, GUARD, TALL=true>: 16 waves per workgroup = 4 per SIMD = 128 VGPRs.  R = 6 without scratch;
+    the larger tiles spill a few field rows around the pass loop's exchange (not in the sweeps -- that is what the row
+    lambda's empty asm and the codes in LDS are for: without them R = 12 needed 1 KiB of scratch and ran 12x slower);
+    LDS = dictionary + 64 KiB mailbox + 256 B of codes per tile row, under the CU's 160 KiB."""
+    budget = {6: 0, 8: 64, 10: 192, 12: 288, 14: 400}
+    seen = set()
+    for name, u in usage.items():
+        m = re.match(r"_ZN4deff13k_sweep_wgresILi8ELi(\d+)ELb[01]ELb[01]ELb1EEE", name)
+        if not m:
+            continue
+        R = int(m.group(1))
+        seen.add(R)
+        assert u["Occupancy"] >= 4 and u["VGPRs"] <= 128 and u["AGPRs"] == 0, (name, u)
+        assert u["ScratchSize"] <= budget[R], (name, u)
+        assert u["LDS"] <= 160 * 1024 and u["LDS"] >= 24 * 1024 + 64 * 1024 + 16 * R * 256, (name, u)
+    assert seen == set(budget)
 
 
 def test_single_sweep_kernels_are_light(usage):
