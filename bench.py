@@ -333,6 +333,17 @@ def main():
             s2.sweeps(960, args.omega)
             ms2 = min(s2.sweeps(4800, args.omega) for _ in range(3))
             small = (1024.0 * 1024.0 * 4800 / (ms2 * 1e-3) / 1e6, s2.kernel_in_use(), s2.plan())
+    # fifth row: ONE 2048^2 image -- the middle of the size range, where the planner keeps the image resident on tall
+    # workgroup tiles (kernels_wgtile.hpp) instead of streaming it
+    mid = None
+    if rank == 0 and n != 2048 and args.batch == 1 and not args.no_small_image:
+        with pkg.Solver(2048, 2048, device=local_rank, kernel=args.kernel) as s3:
+            s3.synth_image(12345, 0)
+            s3.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            s3.init_linear(0.0, 1.0)
+            s3.sweeps(480, args.omega)
+            ms3 = min(s3.sweeps(2400, args.omega) for _ in range(3))
+            mid = (2048.0 * 2048.0 * 2400 / (ms3 * 1e-3) / 1e6, s3.kernel_in_use(), s3.plan())
 
     if rank == 0:
         cells = float(n) * n * args.batch
@@ -446,6 +457,10 @@ def main():
                                         "fp64_instr_frac": FP64_INSTR_PER_CELL[False] * small[0] * 1e6 / 1e12 / FP64_INSTR_PEAK_T,
                                         "sample": "4800 sweeps (best of 3) of ONE 1024x1024 synthetic image (BASELINE config #2's "
                                                   "shape), same physics, one GPU"}
+        if mid:
+            out["single_image_2048"] = {"value": mid[0], "unit": "Mcells*iter/s", "kernel": mid[1], "plan": mid[2],
+                                        "fp64_instr_frac": FP64_INSTR_PER_CELL[False] * mid[0] * 1e6 / 1e12 / FP64_INSTR_PEAK_T,
+                                        "sample": "2400 sweeps (best of 3) of ONE 2048x2048 synthetic image, same physics, one GPU"}
         if world == 1 and not args.no_cpu_baseline:
             base, K, want = cpu_baseline(n)
             out["cpu_baseline"] = base

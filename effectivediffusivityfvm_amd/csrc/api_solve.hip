@@ -233,6 +233,9 @@ static void tile_grid(const deff_ctx *c, int cols_per_block, int rows, SweepPlan
 // 682 / 678, 4096^2 1 128 / 742; stacks 16 x 128^2 117 / 239, 64 x 128^2 364 / 683, 200 x 128^2 589 / 652, 16 x 256^2
 // 322 / 418, 48 x 256^2 535 / 535, 12 x 512^2 509 / 618, 2 x 1024^2 426 / 569, 3 x 1024^2 577 / 623 (and 1 024 x 128^2,
 // 16 Mi cells, whole images per wave with no halo: 1 222 streaming).
+// Since the resident forms (k_sweep_wgres) the numbers above are those of ONE LAUNCH PER PASS; with all tiles on the chip
+// one image runs at 512^2 306, 1024^2 840-855 (8-wave tiles), 1536^2 835-866, 2048^2 933-958, 2304^2 958-966 (tall tiles,
+// which plan_sweeps() also takes just above this threshold when they fit), 2 x 1024^2 958, 16 x 512^2 998.
 // Keyed on tb_ref_cells for slabs, so that every slab of an image takes the same decision (and the same T).
 int default_tb_impl(const deff_ctx *c)
 {
