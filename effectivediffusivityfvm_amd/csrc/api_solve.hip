@@ -87,14 +87,16 @@ static int wgt_resident_blocks(const deff_ctx *c, int T, int R, bool fma, bool g
 // tall resident tiles (kernels_wgtile.hpp: 16 waves, matrix rows looked up in every sweep): T = 8, R in WGL_ROWS
 #define WGL_DISPATCH(R_, F_, G_, CALL)                                                          \
     do {                                                                                       \
-        if ((R_) == 6) { WGT_DISPATCH_FG(8, 6, F_, G_, CALL) }                                  \
+        if ((R_) == 4) { WGT_DISPATCH_FG(8, 4, F_, G_, CALL) }                                  \
+        else if ((R_) == 5) { WGT_DISPATCH_FG(8, 5, F_, G_, CALL) }                             \
+        else if ((R_) == 6) { WGT_DISPATCH_FG(8, 6, F_, G_, CALL) }                             \
         else if ((R_) == 8) { WGT_DISPATCH_FG(8, 8, F_, G_, CALL) }                             \
         else if ((R_) == 10) { WGT_DISPATCH_FG(8, 10, F_, G_, CALL) }                           \
         else if ((R_) == 12) { WGT_DISPATCH_FG(8, 12, F_, G_, CALL) }                           \
         else { WGT_DISPATCH_FG(8, 14, F_, G_, CALL) }                                           \
     } while (0)
 // (R = 16 -- 256-row tiles, images up to ~2600^2 -- spills inside the sweep loop: 9.9 us per sweep, slower than streaming)
-static const int WGL_ROWS[] = {6, 8, 10, 12, 14};
+static const int WGL_ROWS[] = {4, 5, 6, 8, 10, 12, 14};
 static bool wgl_has_R(int R) { for (int r : WGL_ROWS) if (r == R) return true; return false; }
 
 template <int T, int R, bool F, bool G>

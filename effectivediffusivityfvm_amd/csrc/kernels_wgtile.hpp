@@ -336,7 +336,7 @@ __global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgtile(const double
 // and the matrix rows are looked up in the dictionary in every sweep, like the streaming kernel does (tb_pair) -- four
 // waves per SIMD hide those lookups.  A tile is 16R rows x 128
 // columns (R = 12: 192 rows, 176 x 112 owned = 80 % of the cells it sweeps; the 8-wave tiles own 62 %), which is what puts
-// images between 1024^2 and ~2300^2 -- too many 56-row tiles for residency, too few cells for tall streaming chunks --
+// images between 1024^2 and ~2300^2 (R = 4 ... 14) -- too many 56-row tiles for residency, too few cells for tall streaming chunks --
 // on the chip all at once.  Same mailbox, one barrier per sweep, rows updated in place top to bottom, interior rows before
 // the barrier as in the 8-wave form (barrier first and no saved copies of rows 1 and R-2: 4-8 VGPRs less, measured 8 %
 // SLOWER at R = 6...12 -- the interior rows do cover the wait).

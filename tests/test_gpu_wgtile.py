@@ -320,7 +320,7 @@ def test_resident_passes_with_a_second_context_loading_the_gpu(pkg):
 TALL_SHAPES = [(300, 200), (1030, 137), (600, 700), (250, 333), (2, 164), (97, 241), (1281, 410), (122, 9)]
 
 
-@pytest.mark.parametrize("R", [6, 8, 10, 12, 14])
+@pytest.mark.parametrize("R", [4, 5, 6, 8, 10, 12, 14])
 @pytest.mark.parametrize("shape", TALL_SHAPES)
 def test_tall_tiles_vs_oracle(pkg, oracle, shape, R):
     """k_sweep_wgres<.., TALL>: every R, ragged strips and row tiles, images shorter than one tile, one-cell-wide
@@ -350,7 +350,7 @@ def test_tall_tiles_vs_oracle(pkg, oracle, shape, R):
         assert_field(s.get_field(), want2)
 
 
-@pytest.mark.parametrize("R", [6, 12, 14])
+@pytest.mark.parametrize("R", [4, 6, 12, 14])
 def test_tall_tiles_omega_one_boundary_values_fma_and_launch_modes(pkg, oracle, R):
     nx, ny = 300, 450
     rng = np.random.default_rng(R)
