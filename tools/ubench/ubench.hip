@@ -6,6 +6,7 @@
 // (-ffp-contract=off matters for k_level: contracted, a level is 14 FP64 instructions instead of 22 and costs 71-86 clocks
 // instead of 109-219; DESIGN.md quotes the uncontracted figures).   ./ubench      instruction rates
 //                                                                   ./ubench mem  HBM streams by read / write mix
+//                                                                   ./ubench clk  shader clock under FP64 / LDS load
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <cstdio>
@@ -203,6 +204,62 @@ static double time_ms(F launch)
     return ms;
 }
 
+// ---- shader clock under load (./ubench clk): clock64() (shader cycles) against wall_clock64() (100 MHz) around a long
+// FP64 / LDS loop -- do the SIMDs really run at the 2.4 GHz that "clocks per instruction" figures assume?
+template <int MODE>
+__global__ __launch_bounds__(256) void k_clk(double *out, unsigned long long *stamps, int iters, double a)
+{
+    __shared__ double tab[2048];
+    for (int i = threadIdx.x; i < 2048; i += 256) tab[i] = 1.0 / (1.0 + i);
+    __syncthreads();
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+    double x0 = threadIdx.x * 1e-3, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    for (int i = 0; i < iters; ++i) {
+        if (MODE >= 1) {                                            // FP64 adds / muls on VGPR pairs, 8 chains
+            x0 = x0 * a + x4; x1 = x1 * a + x5; x2 = x2 * a + x6; x3 = x3 * a + x7;
+            x4 = x4 * a + x0; x5 = x5 * a + x1; x6 = x6 * a + x2; x7 = x7 * a + x3;
+        }
+        if (MODE == 2) {                                            // + LDS reads
+            x0 += tab[(threadIdx.x * 7 + i) & 2047]; x1 += tab[(threadIdx.x * 13 + i) & 2047];
+        }
+        if (MODE == 0) __builtin_amdgcn_s_sleep(8);
+    }
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = w1 - w0; }
+    out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+}
+
+static int clk_main()
+{
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    double *out; unsigned long long *st;
+    CHECK(hipMalloc(&out, sizeof(double) * 256 * cus * 8));
+    CHECK(hipMalloc(&st, sizeof(unsigned long long) * 2 * cus * 8));
+    std::vector<unsigned long long> h(2 * cus * 8);
+    printf("%s: %d CUs, clockRate %.0f MHz; shader MHz = clock64 delta / (wall_clock64 delta / 100 MHz)\n", prop.gcnArchName, cus, prop.clockRate * 1e-3);
+    auto run = [&](const char *name, auto kern, int wg_per_cu, int iters) {
+        const int blocks = cus * wg_per_cu;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, st, iters, 1.0000001);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(h.data(), st, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost));
+        double lo = 1e9, hi = 0, sum = 0, us = 0;
+        for (int b = 0; b < blocks; ++b) {
+            const double mhz = (double)h[2 * b] / ((double)h[2 * b + 1] / 100.0);
+            lo = mhz < lo ? mhz : lo; hi = mhz > hi ? mhz : hi; sum += mhz; us += h[2 * b + 1] / 100.0;
+        }
+        printf("  %-26s %d wave/SIMD: %7.0f MHz mean (%.0f .. %.0f), %.0f us per workgroup\n", name, wg_per_cu, sum / blocks, lo, hi, us / blocks);
+    };
+    for (int w : {1, 2, 4}) {
+        run("idle (s_sleep)", k_clk<0>, w, 20000);
+        run("FP64 mul+add", k_clk<1>, w, 400000);
+        run("FP64 mul+add + LDS reads", k_clk<2>, w, 400000);
+    }
+    CHECK(hipFree(out)); CHECK(hipFree(st));
+    return 0;
+}
+
 static int mem_main(int side)
 {
     hipDeviceProp_t prop;
@@ -237,6 +294,7 @@ static int mem_main(int side)
 int main(int argc, char **argv)
 {
     if (argc > 1 && !strcmp(argv[1], "mem")) return mem_main(argc > 2 ? atoi(argv[2]) : 4096);
+    if (argc > 1 && !strcmp(argv[1], "clk")) return clk_main();
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
