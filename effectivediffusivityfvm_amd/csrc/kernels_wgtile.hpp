@@ -339,7 +339,8 @@ __global__ __launch_bounds__(WGT_WAVES * 64, 2) void k_sweep_wgtile(const double
 // images between 1024^2 and ~2300^2 (R = 4 ... 14) -- too many 56-row tiles for residency, too few cells for tall streaming chunks --
 // on the chip all at once.  Same mailbox, one barrier per sweep, rows updated in place top to bottom, interior rows before
 // the barrier as in the 8-wave form (barrier first and no saved copies of rows 1 and R-2: 4-8 VGPRs less, measured 8 %
-// SLOWER at R = 6...12 -- the interior rows do cover the wait).
+// SLOWER at R = 6...12 -- the interior rows do cover the wait; the lookups of row r + 1 issued before the arithmetic of
+// row r where R <= 8 leaves 24 VGPRs for them: +-0, as in the streaming kernel).
 constexpr int WGL_WAVES = 16;
 constexpr int wgl_rows_owned(int T, int R) { return WGL_WAVES * R - 2 * T; }
 
