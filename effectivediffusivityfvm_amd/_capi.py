@@ -18,7 +18,7 @@ KERNEL_NAMES = {"auto": 0, "explicit": 1, "scalar": 2, "matfree": 3, "matfree_tb
 # every symbol include/deff_amd.h declares (tests check the library exports them all)
 SYMBOLS = [
     "deff_version", "deff_last_error", "deff_error_string", "deff_device_count",
-    "deff_create", "deff_create_batch", "deff_batch_size", "deff_destroy", "deff_mesh", "deff_set_kernel", "deff_get_kernel",
+    "deff_create", "deff_create_batch", "deff_batch_size", "deff_recommended_batch", "deff_destroy", "deff_mesh", "deff_set_kernel", "deff_get_kernel",
     "deff_set_tuning", "deff_get_plan", "deff_set_image", "deff_synth_image", "deff_get_image",
     "deff_load_jpeg_gray", "deff_free", "deff_assemble_2phase", "deff_assemble_3phase", "deff_flood_fill", "deff_assemble_from_D", "deff_set_system", "deff_get_system",
     "deff_init_linear", "deff_set_field", "deff_get_field", "deff_solve", "deff_solve_batch", "deff_sweeps",
@@ -74,6 +74,7 @@ def load():
     L.deff_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(ctx)]
     L.deff_create_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ctx)]
     L.deff_batch_size.argtypes = [ctx, C.POINTER(C.c_int)]
+    L.deff_recommended_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int)]
     L.deff_destroy.argtypes = [ctx]
     L.deff_mesh.argtypes = [ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
                             C.POINTER(C.c_double)]

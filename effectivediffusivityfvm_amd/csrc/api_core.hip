@@ -9,6 +9,7 @@
 // ping-pong (no per-sweep sync or D2D copy, unlike cuh:1239/cuh:1281); a
 // convergence check moves 16*ny bytes, not the field (cuh:1245).
 #include "ctx.hpp"
+#include <algorithm>
 #include "driver/jpeg_gray.hpp"
 #include "flood_fill.hpp"
 
@@ -141,6 +142,36 @@ try {
     if (ny) *ny = c->ny;
     if (dx) *dx = c->dx;
     if (dy) *dy = c->dy;
+    return DEFF_OK;
+}
+DEFF_API_CATCH
+
+// How many images of an nx x ny mesh a stack context (deff_create_batch + deff_solve_stream) should hold on `device` when
+// `images` of them are to be solved -- the planner's knowledge, so that callers need not copy it:
+//   - an image that is ONE tall tile (one 128-column strip, at most 16 x 14 rows: kernels_wgtile.hpp) -- one image per CU:
+//     every image stays in the registers of its workgroup between two checks, nothing is recomputed, nobody waits
+//     (256 x 128^2: 1 472 G cells*iter/s against 1 277 for 1 024 slots and 1 347 for 4 096 on the streaming kernel);
+//   - otherwise a stack of ~16 Mi cells for the streaming kernel, ~64 Mi cells when the images outnumber such a stack
+//     several times (whole images per wave, nothing recomputed; a shorter run would spend its time draining).
+extern "C" int deff_recommended_batch(int device, int nx, int ny, int64_t images, int *slots)
+try {
+    if (!slots || nx < 2 || ny < 2 || images < 1) return fail(DEFF_EINVAL, "bad argument");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(DEFF_ENODEV, "no such device");
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    const int nxp = (nx + 1) & ~1;
+    int64_t want;
+    if (nxp <= 128 && ny <= 16 * 14 && cus >= 8) {
+        want = cus / 8 * 8;
+    } else {
+        const int64_t cells = (int64_t)nxp * ny;
+        const int64_t big = ((int64_t)64 << 20) / cells, small = std::max<int64_t>(1, ((int64_t)16 << 20) / cells);
+        want = (big >= 1 && images >= 3 * big) ? big : small;
+    }
+    want = std::min<int64_t>(std::min<int64_t>(want, images), 4096);
+    *slots = (int)std::max<int64_t>(1, want);
     return DEFF_OK;
 }
 DEFF_API_CATCH

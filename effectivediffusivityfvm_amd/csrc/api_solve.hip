@@ -97,6 +97,18 @@ static int wgt_resident_blocks(const deff_ctx *c, int T, int R, bool fma, bool g
     } while (0)
 // (R = 16 -- 256-row tiles, images up to ~2600^2 -- spills inside the sweep loop: 9.9 us per sweep, slower than streaming)
 static const int WGL_ROWS[] = {4, 5, 6, 8, 10, 12, 14};
+// Row tiles a tall-tile image of own_h rows needs at R rows per wave.  A tall tile carries no halo rows beyond a wall of
+// the mesh (its rows start at the image's first row, kernels_wgtile.hpp), so ONE tile holds 16R rows, two tiles 16R - T
+// each, three or more 16R - 2T (the inner ones).  A 128^2 image of a stack is one tile of 16 x 8 rows: nothing recomputed,
+// nobody to wait for.
+static int wgl_row_tiles(int own_h, int R, int T)
+{
+    const int rows = WGL_WAVES * R;
+    if (own_h <= rows) return 1;
+    if (own_h <= 2 * (rows - T)) return 2;
+    const int lymax = rows - 2 * T;
+    return (own_h + lymax - 1) / lymax;
+}
 static bool wgl_has_R(int R) { for (int r : WGL_ROWS) if (r == R) return true; return false; }
 
 template <int T, int R, bool F, bool G>
@@ -374,8 +386,7 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
                 c->n * sizeof(double) < ((size_t)1 << 31)) {
                 for (int R : WGL_ROWS) {
                     if (c->tb_NW == WGL_WAVES && wgl_has_R(c->tb_R) && R != c->tb_R) continue;
-                    const int lymax = wgl_rows_owned(T, R);
-                    const long tiles = (long)pl->ntx * ((own_h + lymax - 1) / lymax) * c->nimg;
+                    const long tiles = (long)pl->ntx * wgl_row_tiles(own_h, R, T) * c->nimg;
                     int res = 0;
                     TRY(wgl_resident_blocks(c, R, pl->fma, c->lut_guard, &res));
                     if (((tiles + 7) / 8) * 8 <= res) { tall_R = R; break; }
@@ -445,8 +456,7 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
                 if (tall_R && (!pl->resident || c->tb_NW == WGL_WAVES)) {
                     pl->R = tall_R;
                     pl->NW = WGL_WAVES;
-                    const int lymaxL = wgl_rows_owned(T, tall_R);
-                    int cpiL = (own_h + lymaxL - 1) / lymaxL;
+                    const int cpiL = wgl_row_tiles(own_h, tall_R, T);
                     pl->LY = (own_h + cpiL - 1) / cpiL;
                     pl->tcpi = (own_h + pl->LY - 1) / pl->LY;
                     pl->tgy = pl->tcpi * c->nimg;

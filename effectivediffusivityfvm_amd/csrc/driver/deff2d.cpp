@@ -636,12 +636,17 @@ int main(int argc, char **argv)
             // where every wave sweeps a whole image with nothing recomputed (128^2: 1 347 against
             // 1 113 G cells*iter/s) -- only when the images outnumber the slots several times, or the
             // stream would spend its time draining
-            const long long cells = (long long)nx * ny;
+            // (since the tall resident tiles: an image that fits ONE workgroup tile gets one slot per CU instead -- the
+            // rule lives in the library: deff_recommended_batch)
             const long long per_dev = (count + (long long)std::max<size_t>(1, devices.size()) - 1) / (long long)std::max<size_t>(1, devices.size());
-            const long long big = (64ll << 20) / cells, small = std::max<long long>(1, (16ll << 20) / cells);
-            long long want = batch_size > 0 ? batch_size : (big >= 1 && per_dev >= 3 * big ? big : small);
-            want = std::min<long long>(want, std::max<long long>(1, per_dev));
-            const int slots = (int)std::min<long long>(want, 4096);
+            int slots = 1;
+            if (batch_size > 0) {
+                slots = (int)std::min<long long>(std::min<long long>(batch_size, std::max<long long>(1, per_dev)), 4096);
+            } else if (deff_recommended_batch(dev, nx, ny, std::max<long long>(1, per_dev), &slots) != DEFF_OK) {
+                std::fprintf(stderr, "deff2d: %s\n", deff_last_error());
+                failed = true;
+                return;
+            }
             if (deff_create_batch(dev, nx, ny, slots, &st.ctx) != DEFF_OK ||
                 deff_set_tuning(st.ctx, "fma", g_contracted) != DEFF_OK) {
                 std::fprintf(stderr, "deff2d: %s\n", deff_last_error());

@@ -522,7 +522,9 @@ __global__ __launch_bounds__((TALL ? WGL_WAVES : WGT_WAVES) * 64, (TALL ? 4 : 2)
     const int own0 = own_lo + img * img_stride;
     const int ry0 = own0 + (bty - img * cpi) * ly;
     const int ry1 = min(ry0 + ly, own0 + own_h);
-    const int w0 = ry0 - T + wave * R;
+    // a tall tile keeps no rows above the first row of its image (there is no halo beyond a wall): its 16R rows then reach
+    // T rows further down, which is what lets ONE tile hold a whole 128-row image (api_solve.hip, wgl_row_tiles)
+    const int w0 = (TALL ? max(ry0 - T, row_lo) : ry0 - T) + wave * R;
     const int ld_lo = max(ry0 - T, row_lo), ld_hi = min(ry1 + T, row_hi);
     const int col = tx * WOUT - shift + 2 * lane;
     const bool in_x = col >= 0 && col < nx;
@@ -543,6 +545,10 @@ __global__ __launch_bounds__((TALL ? WGL_WAVES : WGT_WAVES) * 64, (TALL ? 4 : 2)
         if (tx2 >= 0 && tx2 < ntx && by2 >= img * cpi && by2 < (img + 1) * cpi)
             nb = xmajor ? by2 * ntx + tx2 : tx2 * gy + by2;
     }
+
+    // a tile that is a whole image (one strip, one row tile: a 128^2 image of a stack on a tall tile) has nobody to
+    // exchange with: it neither stores its rim nor raises a flag between passes
+    const bool alone = !__syncthreads_or(nb >= 0);
 
     double2 xr[R];
     unsigned cc[R];
@@ -621,6 +627,7 @@ __global__ __launch_bounds__((TALL ? WGL_WAVES : WGT_WAVES) * 64, (TALL ? 4 : 2)
             if constexpr (TALL) wgl_sweeps<T, R, FMA, GUARD, WALL>(xr, codes_lds + wave * R * 64 + lane, lut, edge, par, wave, lane, w0, ry0, ry1, row_lo, row_hi, omw);
             else wgt_sweeps<T, R, FMA, GUARD, WALL>(xr, k, bb, edge, par, wave, lane, w0, ry0, ry1, row_lo, row_hi, omw, nullptr);
             if (st && p < 3) st[4 * p + 2] = wall_clock64();
+            if (alone && !last) continue;                          // workgroup-uniform
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int rr = w0 + r;

@@ -22,6 +22,13 @@ class SolveResult:
                 f"conv={self.conv!r}, loop_ms={self.loop_ms:.3f})")
 
 
+def recommended_batch(nx, ny, images, device=0):
+    """Slots a stack Solver(nx, ny, nimg=...) should have to solve `images` images (deff_recommended_batch)."""
+    n = C.c_int()
+    check(_capi.load().deff_recommended_batch(int(device), int(nx), int(ny), int(images), C.byref(n)))
+    return n.value
+
+
 class Solver:
     """One context: `nimg` images of an nx x ny mesh (nimg > 1 = dataset-generation batch,
     arrays are then stacked image after image: shape (nimg*ny, nx))."""

@@ -71,6 +71,9 @@ int deff_create(int device, int nx, int ny, deff_ctx **out);
  * those of a one-at-a-time run. */
 int deff_create_batch(int device, int nx, int ny, int nimg, deff_ctx **out);
 int deff_batch_size(const deff_ctx *ctx, int *nimg);
+/* how many slots a stack context for `images` images of an nx x ny mesh should have on `device` (dataset generation:
+ * small images that fit one workgroup tile get one slot per CU and stay resident; otherwise ~16-64 Mi cells per stack) */
+int deff_recommended_batch(int device, int nx, int ny, int64_t images, int *slots);
 int deff_destroy(deff_ctx *ctx);
 int deff_mesh(const deff_ctx *ctx, int *nx, int *ny, double *dx, double *dy);   /* meshInfo cuh:54-61 */
 int deff_set_kernel(deff_ctx *ctx, int kernel);

@@ -342,7 +342,8 @@ def test_tall_tiles_vs_oracle(pkg, oracle, shape, R):
         s.sweeps(43)
         p = s.plan()
         assert (p["tb_impl"], p["tb_NW"], p["tb_R"], p["tb_T"], p["tb_resident"]) == (2, 16, R, 8, 1), p
-        assert 1 <= p["tb_LY"] <= 16 * R - 16 and p["tb_LY"] * p["tb_chunks_per_image"] >= ny
+        cpi = p["tb_chunks_per_image"]                        # no halo rows beyond a wall: 1 tile holds 16R rows, 2 tiles 16R - 8 each
+        assert 1 <= p["tb_LY"] <= 16 * R - 8 * min(cpi - 1, 2) and p["tb_LY"] * cpi >= ny
         launches, _ = s.last_launches()
         assert launches == 1 + 3
         assert_field(s.get_field(), want1)
@@ -464,3 +465,52 @@ def test_2048_default_plan_is_tall_and_matches_the_oracle(pkg, oracle):
             assert_field(s.get_field(), want)
             d, MFL, MFR = s.flux()
             assert d == dor and np.array_equal(MFL, MFLo) and np.array_equal(MFR, MFRo)
+
+
+def test_tall_tiles_whole_image_per_tile(pkg, oracle):
+    """A stack of 128 x 128 images on tall tiles: ONE tile per image (16 waves x 8 rows, no halo beyond the walls), no
+    neighbour to exchange with (rim stores and flags are skipped between passes), images stopping at different checks;
+    iteration counts, Deff and fields against one-image-at-a-time oracle solves.  Also two tiles per image (128 x 200)."""
+    for (nx, ny, B, R) in ((128, 128, 6, 8), (128, 200, 3, 8), (96, 64, 5, 4)):
+        rng = np.random.default_rng(nx + ny + B)
+        pixs = [rand_mask(rng, nx, ny, 0.35 + 0.08 * k) for k in range(B)]
+        with pkg.Solver(nx, ny, nimg=B, kernel="matfree_tb") as s:
+            s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 16); s.set_tuning("tb_R", R)
+            s.set_image(np.stack(pixs))
+            s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+            s.init_linear(0.0, 1.0)
+            res = s.solve(1e-3, 6000, check_every=200)
+            got = s.get_field()
+            p = s.plan()
+            assert (p["tb_NW"], p["tb_R"], p["tb_resident"], p["tb_strips"]) == (16, R, 1, 1), p
+            assert p["tb_chunks_per_image"] == (1 if ny <= 16 * R else 2)
+        iters = set()
+        for k in range(B):
+            D = oracle.fill_D_2phase(pixs[k], 1.0, 1e-2)
+            A, b = oracle.discretize(D, 0.0, 1.0)
+            it, deff, conv, x, _, _ = oracle.jacobi(A, b, oracle.linear_guess(nx, ny, 0.0, 1.0), D, 0.0, 1.0, 1e-3, 6000,
+                                                    check_every=200)
+            assert (res[k].iters, res[k].deff_raw, res[k].conv) == (it, deff, conv)
+            assert_field(got[k * ny:(k + 1) * ny], x)
+            iters.add(it)
+        assert len(iters) > 1
+
+
+def test_recommended_batch(pkg):
+    """deff_recommended_batch: one slot per CU for images that are one tall tile, cell budgets otherwise."""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert pkg.recommended_batch(128, 128, 100000) == cus // 8 * 8
+    assert pkg.recommended_batch(127, 200, 100000) == cus // 8 * 8
+    assert pkg.recommended_batch(128, 128, 10) == 10
+    assert pkg.recommended_batch(128, 225, 100000) == (64 << 20) // (128 * 225)       # too tall for one tile: streaming stacks
+    assert pkg.recommended_batch(1024, 1024, 1024) == 64
+    assert pkg.recommended_batch(1024, 1024, 100) == 16
+    assert pkg.recommended_batch(16384, 16384, 4) == 1
+    with pkg.Solver(128, 128, nimg=pkg.recommended_batch(128, 128, 100000), kernel="matfree_tb") as s:
+        s.synth_image(1, 0)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(64)
+        p = s.plan()
+        assert (p["tb_NW"], p["tb_R"], p["tb_resident"], p["tb_chunks_per_image"]) == (16, 8, 1, 1), p
