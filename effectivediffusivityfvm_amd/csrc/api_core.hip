@@ -246,6 +246,7 @@ try {
     else if (!strcmp(key, "tb_impl")) c->tb_impl = value > 2 ? 0 : value;
     else if (!strcmp(key, "tb_R")) c->tb_R = value;
     else if (!strcmp(key, "tb_debug_stall")) c->tb_debug_stall = value;
+    else if (!strcmp(key, "tb_sym")) c->tb_sym = value;
     else if (!strcmp(key, "tb_launch")) {            // 0 / 2: resident passes where possible (2: cooperative launch); 1: one launch per pass
         c->tb_resident = value == 1 ? 0 : 1;
         c->tb_coop = value == 2 ? 1 : 0;
@@ -274,6 +275,7 @@ try {
     else if (!strcmp(key, "tb_impl")) *value = c->plan_impl;
     else if (!strcmp(key, "tb_R")) *value = c->plan_R;
     else if (!strcmp(key, "tb_resident")) *value = c->plan_resident;
+    else if (!strcmp(key, "tb_sym")) *value = c->links_sym;
     else if (!strcmp(key, "tb_NW")) *value = c->plan_NW;
     else return fail(DEFF_EINVAL, "unknown plan key '%s'", key);
     return DEFF_OK;
@@ -400,6 +402,7 @@ try {
     HIP_TRY(hipGetLastError());
     build_lut_rows(c, Ds, Df, CL, CR);
     c->have_matfree = true;
+    c->links_sym = 0;
 
     // the explicit SoA planes are built on demand (explicit_from_image)
     c->Ds = Ds; c->Df = Df;

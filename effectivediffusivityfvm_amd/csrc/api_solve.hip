@@ -174,7 +174,7 @@ static hipError_t resident_chain_end(const deff_ctx *c)
     return hipEventRecord(g_res_ev[d], c->stream);
 }
 
-template <int T, int R, bool F, bool G, bool TALL = false>
+template <int T, int R, bool F, bool G, bool TALL = false, bool SYM = false>
 static hipError_t launch_wgres(deff_ctx *c, const SweepPlan &pl, double *xa, double *xb, int npass, unsigned base)
 {
     constexpr int THREADS = (TALL ? WGL_WAVES : WGT_WAVES) * 64;
@@ -193,7 +193,7 @@ static hipError_t launch_wgres(deff_ctx *c, const SweepPlan &pl, double *xa, dou
         std::lock_guard<std::mutex> lock(g_res_mu);
         hipError_t e = resident_chain_begin(c);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_sweep_wgres<T, R, F, G, TALL>), dim3(pl.tblocks), dim3(THREADS), 0, c->stream, lut, code, xa,
+        hipLaunchKernelGGL((k_sweep_wgres<T, R, F, G, TALL, SYM>), dim3(pl.tblocks), dim3(THREADS), 0, c->stream, lut, code, xa,
                            xb, nx, ny, img_stride, dom_lo, own_lo, own_h, cpi, ly, mask, ntx, gy, xmajor, allb, nrows, shift,
                            omw, npass, flags, base, abort_flag, xbytes, stall_tile, stamps);
         e = hipPeekAtLastError();
@@ -202,7 +202,7 @@ static hipError_t launch_wgres(deff_ctx *c, const SweepPlan &pl, double *xa, dou
     }
     void *args[] = {&lut, &code, &xa, &xb, &nx, &ny, &img_stride, &dom_lo, &own_lo, &own_h, &cpi, &ly, &mask, &ntx, &gy,
                     &xmajor, &allb, &nrows, &shift, &omw, &npass, &flags, &base, &abort_flag, &xbytes, &stall_tile, &stamps};
-    return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&k_sweep_wgres<T, R, F, G, TALL>), dim3(pl.tblocks),
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&k_sweep_wgres<T, R, F, G, TALL, SYM>), dim3(pl.tblocks),
                                       dim3(THREADS), args, 0, c->stream);
 }
 
@@ -337,6 +337,7 @@ static int try_dict(deff_ctx *c)
     c->lut_allb = flags[2] != 0;
     c->lut_omega = NAN;
     c->have_matfree = true;
+    c->links_sym = 0;
     return DEFF_OK;
 }
 
@@ -476,6 +477,21 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
                     }
                     if (c->coop_launch < 0)
                         HIP_TRY(hipDeviceGetAttribute(&c->coop_launch, hipDeviceAttributeCooperativeLaunch, c->device));
+                    // link symmetry of the system, looked at once per (codes, dictionary): one pass over the codes
+                    if (c->links_sym == 0 && c->tb_sym != 2) {
+                        unsigned h = 1;
+                        TRY(resident_check(c));                    // (the abort word doubles as this kernel's flag: read it first)
+                        unsigned *flag = c->res_abort;
+                        HIP_TRY(hipMemsetAsync(flag, 0, sizeof(unsigned), c->stream));
+                        hipLaunchKernelGGL(k_links_symmetric, dim3(grid_for(c->n, 2048)), dim3(256), 0, c->stream, c->lut, c->code,
+                                           c->nx, c->rows, c->ny, c->lut_nrows, flag);
+                        HIP_TRY(hipGetLastError());
+                        HIP_TRY(hipMemcpyAsync(&h, flag, sizeof h, hipMemcpyDeviceToHost, c->stream));
+                        HIP_TRY(hipMemsetAsync(flag, 0, sizeof(unsigned), c->stream));
+                        HIP_TRY(hipStreamSynchronize(c->stream));
+                        c->links_sym = h ? 2 : 1;
+                    }
+                    pl->sym = c->tb_sym != 2 && c->links_sym == 1;
                 }
                 if (pl->band_h <= 0) {
                     c->plan_T = pl->T; c->plan_LY = pl->LY; c->plan_ntx = pl->ntx; c->plan_cpi = pl->tcpi;
@@ -650,9 +666,13 @@ void enqueue_sweeps(deff_ctx *c, const SweepPlan &pl, int64_t n)
             const int chunk = (int)(np < 4096 ? np : 4096);
             hipError_t e = hipSuccess;
             if (pl.NW == WGL_WAVES) {
-#define LAUNCH_WGL(T_, R_, C_, G_) e = launch_wgres<T_, R_, C_, G_, true>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch)
-                WGL_DISPATCH(pl.R, pl.fma, pl.guard, LAUNCH_WGL);
+                // (the symmetric short-cut exists in the unguarded kernels only: the guarded one branches on every link anyway)
+#define LAUNCH_WGL(T_, R_, C_, G_) e = launch_wgres<T_, R_, C_, G_, true, false>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch)
+#define LAUNCH_WGLS(T_, R_, C_, G_) e = launch_wgres<T_, R_, C_, false, true, true>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch)
+                if (pl.sym && !pl.guard) { WGL_DISPATCH(pl.R, pl.fma, false, LAUNCH_WGLS); }
+                else { WGL_DISPATCH(pl.R, pl.fma, pl.guard, LAUNCH_WGL); }
 #undef LAUNCH_WGL
+#undef LAUNCH_WGLS
             } else {
 #define LAUNCH_WGR(T_, R_, C_, G_) e = launch_wgres<T_, R_, C_, G_>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch)
                 WGT_DISPATCH(pl.T, pl.R, pl.fma, pl.guard, LAUNCH_WGR);
@@ -870,6 +890,7 @@ static int stream_load_slot(deff_ctx *c, int slot, const uint8_t *pix_host)
                        c->x[c->cur] + (size_t)slot * c->n_img, c->nx, c->nxt, c->ny, c->CL, c->CR, c->fma);
     HIP_TRY(hipGetLastError());
     c->buf_of[slot] = (uint8_t)c->cur;
+    c->links_sym = 0;                                  // new codes in this slot
     return DEFF_OK;
 }
 
@@ -912,6 +933,7 @@ try {
     c->CL = CL; c->CR = CR; c->Ds = Ds; c->Df = Df;
     build_lut_rows(c, Ds, Df, CL, CR);
     c->have_image = true; c->have_walls = true; c->have_matfree = true; c->have_explicit = false;
+    c->links_sym = 0;
     c->dict_tried = false; c->have_field = true;
     HIP_TRY(hipMemsetAsync(c->code, 0, sizeof(uint16_t) * c->n, c->stream));      // empty slots: zero rows
     HIP_TRY(hipMemsetAsync(c->x[0], 0, sizeof(double) * c->n, c->stream));

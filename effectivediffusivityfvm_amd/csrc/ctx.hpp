@@ -156,6 +156,10 @@ struct deff_ctx {
     // not the default because ROCm 7.2's teardown segfaults at process exit once several host threads have launched
     // cooperatively (deff2d --devices 0,0,0).
     int tb_resident = 1, tb_coop = 0;
+    // is the matrix-free system link-symmetric (k_links_symmetric)?  0 = not looked at since the codes / dictionary last
+    // changed, 1 = yes (tall tiles then do 7 lookups per row instead of 10), 2 = no
+    int links_sym = 0;
+    int tb_sym = 0;                              // tuning: 2 = never use the symmetric short-cut (A/B, tests)
     int tb_debug_stall = 0;                      // tests: tile (index + 1) that leaves a resident launch without publishing
     int plan_resident = 0;                       // the last plan used resident passes
     unsigned *res_flags = nullptr;               // per tile: passes completed (epoch counter)
@@ -271,6 +275,7 @@ struct SweepPlan {
     bool guard = false;
     int impl = 1, R = 0, NW = 8;                          // 1 = streaming kernel, 2 = workgroup tiles of NW waves x R rows
     bool resident = false;                                // impl 2 only: all passes of a batch in one launch (k_sweep_wgres)
+    bool sym = false;                                     // tall tiles: the system is link-symmetric (7 lookups per row)
     // rows the plan updates: band_h > 0 restricts it to the band [band_lo, band_lo + band_h) of the context's owned rows
     // (input); own_lo / own_h are what the planner resolved (output, passed to the kernels)
     int band_lo = 0, band_h = 0, own_lo = 0, own_h = 0;

@@ -75,7 +75,7 @@ class Solver:
     def plan(self):
         """What the temporally blocked kernel's last launch plan chose (zeros before any sweep)."""
         out = {}
-        for key in ("tb_T", "tb_LY", "tb_strips", "tb_chunks_per_image", "tb_blocks", "tb_impl", "tb_R", "tb_NW", "tb_resident"):
+        for key in ("tb_T", "tb_LY", "tb_strips", "tb_chunks_per_image", "tb_blocks", "tb_impl", "tb_R", "tb_NW", "tb_resident", "tb_sym"):
             v = C.c_int()
             check(self._L.deff_get_plan(self._ctx, key.encode(), C.byref(v)))
             out[key] = v.value
@@ -293,7 +293,7 @@ class SlabGroup:
         out = []
         for r in range(self.nslabs):
             d = {}
-            for key in ("tb_T", "tb_LY", "tb_strips", "tb_chunks_per_image", "tb_blocks", "tb_impl", "tb_R", "tb_NW", "tb_resident"):
+            for key in ("tb_T", "tb_LY", "tb_strips", "tb_chunks_per_image", "tb_blocks", "tb_impl", "tb_R", "tb_NW", "tb_resident", "tb_sym"):
                 v = C.c_int()
                 check(self._L.deff_slab_group_get_plan(self._g, r, key.encode(), C.byref(v)))
                 d[key] = v.value

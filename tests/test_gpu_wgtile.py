@@ -514,3 +514,62 @@ def test_recommended_batch(pkg):
         s.sweeps(64)
         p = s.plan()
         assert (p["tb_NW"], p["tb_R"], p["tb_resident"], p["tb_chunks_per_image"]) == (16, 8, 1, 1), p
+
+
+def test_tall_tiles_symmetric_shortcut_is_verified_not_assumed(pkg, oracle):
+    """Tall tiles do 7 lookups per row instead of 10 when the system is link-symmetric (a lane's second cell takes its W
+    link from the first cell's E link, a row its N links from the S links of the row above).  That is checked on the
+    device for the system at hand (k_links_symmetric; plan key tb_sym: 1 symmetric, 2 not): the native assembly passes;
+    a host matrix whose E links were scaled without their W counterparts must not, and still gives its own oracle's bits;
+    tb_sym = 2 switches the short-cut off."""
+    rng = np.random.default_rng(314)
+    nx, ny = 300, 260
+    pix = rand_mask(rng, nx, ny, 0.5)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-2)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    x0 = rng.random((ny, nx))
+    want = oracle.sweeps(A, b, x0, 27)
+    for off in (0, 2):
+        with pkg.Solver(nx, ny, kernel="matfree_tb") as s:
+            s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 16); s.set_tuning("tb_R", 8); s.set_tuning("tb_sym", off)
+            s.set_image(pix)
+            s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+            s.set_field(x0)
+            s.sweeps(27)
+            p = s.plan()
+            assert p["tb_NW"] == 16 and p["tb_sym"] == (1 if off == 0 else 0), p
+            assert_field(s.get_field(), want)
+    # the same matrix through the seam (harvested dictionary): still symmetric
+    with pkg.Solver(nx, ny) as s:
+        s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 16); s.set_tuning("tb_R", 8)
+        s.set_system(A, b, D, 0.0, 1.0)
+        s.set_field(x0)
+        s.sweeps(27)
+        assert s.kernel_in_use() == "matfree_tb" and s.plan()["tb_NW"] == 16 and s.plan()["tb_sym"] == 1
+        assert_field(s.get_field(), want)
+    # E links scaled, W links not: few distinct rows (dictionary), no symmetry
+    A2 = A.copy().reshape(ny, nx, 5)
+    A2[:, :, 2] *= 1.0 + 2.0 ** -10
+    A2 = A2.reshape(A.shape)
+    want2 = oracle.sweeps(A2, b, x0, 27)
+    assert not np.array_equal(want2, want)
+    with pkg.Solver(nx, ny) as s:
+        s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 16); s.set_tuning("tb_R", 8)
+        s.set_system(A2, b, D, 0.0, 1.0)
+        s.set_field(x0)
+        s.sweeps(27)
+        p = s.plan()
+        assert s.kernel_in_use() == "matfree_tb" and p["tb_NW"] == 16 and p["tb_sym"] == 2, p
+        assert_field(s.get_field(), want2)
+    # N links scaled: the vertical half of the check
+    A3 = A.copy().reshape(ny, nx, 5)
+    A3[:, :, 4] *= 1.0 - 2.0 ** -11
+    A3 = A3.reshape(A.shape)
+    want3 = oracle.sweeps(A3, b, x0, 27)
+    with pkg.Solver(nx, ny) as s:
+        s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 16); s.set_tuning("tb_R", 8)
+        s.set_system(A3, b, D, 0.0, 1.0)
+        s.set_field(x0)
+        s.sweeps(27)
+        assert s.plan()["tb_sym"] == 2
+        assert_field(s.get_field(), want3)

@@ -68,7 +68,7 @@ def test_resident_kernel_fits_two_waves_per_simd(usage):
     for R, scratch in ((4, 0), (6, 0), (7, 64)):
         for T in (4, 8):
             for name, u in kernels(usage, f"_ZN4deff13k_sweep_wgresILi{T}ELi{R}E").items():
-                m = re.search(r"ELb[01]ELb([01])ELb([01])EEE", name)           # <.., FMA, GUARD, TALL>
+                m = re.search(r"ELb[01]ELb([01])ELb([01])ELb[01]EEE", name)    # <.., FMA, GUARD, TALL, SYM>
                 if m.group(2) == "1":
                     continue                                         # the tall form, checked below
                 guard = m.group(1) == "1"                            # zero-diffusivity variant: SGPR-heavy branches
@@ -85,7 +85,7 @@ def test_tall_resident_kernel_fits_four_waves_per_simd(usage):
     budget = {4: 0, 5: 0, 6: 0, 8: 64, 10: 192, 12: 288, 14: 400}
     seen = set()
     for name, u in usage.items():
-        m = re.match(r"_ZN4deff13k_sweep_wgresILi8ELi(\d+)ELb[01]ELb[01]ELb1EEE", name)
+        m = re.match(r"_ZN4deff13k_sweep_wgresILi8ELi(\d+)ELb[01]ELb[01]ELb1ELb[01]EEE", name)
         if not m:
             continue
         R = int(m.group(1))
