@@ -341,6 +341,25 @@ static int try_dict(deff_ctx *c)
     return DEFF_OK;
 }
 
+// Runs k_links_symmetric on the current (dictionary, codes) unless that was done since they last changed; the answer is
+// c->links_sym (1 yes, 2 no).  Needs c->res_abort (its flag word) and synchronises the stream.
+static int check_links_symmetric(deff_ctx *c)
+{
+    if (c->links_sym != 0) return DEFF_OK;
+    unsigned h = 1;
+    TRY(resident_check(c));                                        // the abort word doubles as this kernel's flag: read it first
+    unsigned *flag = c->res_abort;
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL(k_links_symmetric, dim3(grid_for(c->n, 2048)), dim3(256), 0, c->stream, c->lut, c->code, c->nx, c->rows,
+                       c->ny, c->lut_nrows, flag);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&h, flag, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(unsigned), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->links_sym = h ? 2 : 1;
+    return DEFF_OK;
+}
+
 int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
 {
     if (!c->have_field) return fail(DEFF_ESTATE, "no field: call deff_init_linear() or deff_set_field()");
@@ -478,19 +497,7 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
                     if (c->coop_launch < 0)
                         HIP_TRY(hipDeviceGetAttribute(&c->coop_launch, hipDeviceAttributeCooperativeLaunch, c->device));
                     // link symmetry of the system, looked at once per (codes, dictionary): one pass over the codes
-                    if (c->links_sym == 0 && c->tb_sym != 2) {
-                        unsigned h = 1;
-                        TRY(resident_check(c));                    // (the abort word doubles as this kernel's flag: read it first)
-                        unsigned *flag = c->res_abort;
-                        HIP_TRY(hipMemsetAsync(flag, 0, sizeof(unsigned), c->stream));
-                        hipLaunchKernelGGL(k_links_symmetric, dim3(grid_for(c->n, 2048)), dim3(256), 0, c->stream, c->lut, c->code,
-                                           c->nx, c->rows, c->ny, c->lut_nrows, flag);
-                        HIP_TRY(hipGetLastError());
-                        HIP_TRY(hipMemcpyAsync(&h, flag, sizeof h, hipMemcpyDeviceToHost, c->stream));
-                        HIP_TRY(hipMemsetAsync(flag, 0, sizeof(unsigned), c->stream));
-                        HIP_TRY(hipStreamSynchronize(c->stream));
-                        c->links_sym = h ? 2 : 1;
-                    }
+                    if (c->tb_sym != 2) TRY(check_links_symmetric(c));
                     pl->sym = c->tb_sym != 2 && c->links_sym == 1;
                 }
                 if (pl->band_h <= 0) {
@@ -1039,6 +1046,11 @@ try {
             }
         }
         TRY(refill());                                 // newcomers start with the sweep that precedes the next check
+        // new images, new codes: the symmetric short-cut of the tall tiles is re-verified, not carried over
+        if (pl.impl == 2 && pl.NW == WGL_WAVES && c->tb_sym != 2 && c->links_sym == 0) {
+            TRY(check_links_symmetric(c));
+            pl.sym = c->links_sym == 1;
+        }
     }
     c->masked = false;
     reset_batch_state(c);
