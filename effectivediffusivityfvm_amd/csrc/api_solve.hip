@@ -90,13 +90,17 @@ static int wgt_resident_blocks(const deff_ctx *c, int T, int R, bool fma, bool g
         if ((R_) == 4) { WGT_DISPATCH_FG(8, 4, F_, G_, CALL) }                                  \
         else if ((R_) == 5) { WGT_DISPATCH_FG(8, 5, F_, G_, CALL) }                             \
         else if ((R_) == 6) { WGT_DISPATCH_FG(8, 6, F_, G_, CALL) }                             \
+        else if ((R_) == 7) { WGT_DISPATCH_FG(8, 7, F_, G_, CALL) }                             \
         else if ((R_) == 8) { WGT_DISPATCH_FG(8, 8, F_, G_, CALL) }                             \
+        else if ((R_) == 9) { WGT_DISPATCH_FG(8, 9, F_, G_, CALL) }                             \
         else if ((R_) == 10) { WGT_DISPATCH_FG(8, 10, F_, G_, CALL) }                           \
+        else if ((R_) == 11) { WGT_DISPATCH_FG(8, 11, F_, G_, CALL) }                           \
         else if ((R_) == 12) { WGT_DISPATCH_FG(8, 12, F_, G_, CALL) }                           \
+        else if ((R_) == 13) { WGT_DISPATCH_FG(8, 13, F_, G_, CALL) }                           \
         else { WGT_DISPATCH_FG(8, 14, F_, G_, CALL) }                                           \
     } while (0)
 // (R = 16 -- 256-row tiles, images up to ~2600^2 -- spills inside the sweep loop: 9.9 us per sweep, slower than streaming)
-static const int WGL_ROWS[] = {4, 5, 6, 8, 10, 12, 14};
+static const int WGL_ROWS[] = {4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14};
 // Row tiles a tall-tile image of own_h rows needs at R rows per wave.  A tall tile carries no halo rows beyond a wall of
 // the mesh (its rows start at the image's first row, kernels_wgtile.hpp), so ONE tile holds 16R rows, two tiles 16R - T
 // each, three or more 16R - 2T (the inner ones).  A 128^2 image of a stack is one tile of 16 x 8 rows: nothing recomputed,

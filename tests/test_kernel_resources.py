@@ -82,7 +82,7 @@ def test_tall_resident_kernel_fits_four_waves_per_simd(usage):
     the larger tiles spill a few field rows around the pass loop's exchange (not in the sweeps -- that is what the row
     lambda's empty asm and the codes in LDS are for: without them R = 12 needed 1 KiB of scratch and ran 12x slower);
     LDS = dictionary + 64 KiB mailbox + 256 B of codes per tile row, under the CU's 160 KiB."""
-    budget = {4: 0, 5: 0, 6: 0, 8: 64, 10: 192, 12: 288, 14: 400}
+    budget = {4: 0, 5: 0, 6: 0, 7: 0, 8: 64, 9: 128, 10: 192, 11: 256, 12: 288, 13: 320, 14: 400}
     seen = set()
     for name, u in usage.items():
         m = re.match(r"_ZN4deff13k_sweep_wgresILi8ELi(\d+)ELb[01]ELb[01]ELb1ELb[01]EEE", name)
