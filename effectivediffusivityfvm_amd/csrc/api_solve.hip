@@ -124,12 +124,24 @@ static int wgl_occ(int *per_cu)
 
 static int wgl_resident_blocks(const deff_ctx *c, int R, bool fma, bool guard, int *resident)
 {
+    // asked for every candidate R by every plan: remembered per (device, R, arithmetic, guard)
+    static std::mutex mu;
+    static int cache[64][16][4];
+    const int d = c->device, key = (fma ? 2 : 0) + (guard ? 1 : 0);
+    if (d >= 0 && d < 64 && R >= 0 && R < 16) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (cache[d][R][key] > 0) { *resident = cache[d][R][key]; return DEFF_OK; }
+    }
     int per_cu = 0, cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
 #define OCC_CALL(T_, R_, C_, G_) TRY((wgl_occ<T_, R_, C_, G_>(&per_cu)))
     WGL_DISPATCH(R, fma, guard, OCC_CALL);
 #undef OCC_CALL
     *resident = per_cu * cus;
+    if (d >= 0 && d < 64 && R >= 0 && R < 16 && *resident > 0) {
+        std::lock_guard<std::mutex> lock(mu);
+        cache[d][R][key] = *resident;
+    }
     return DEFF_OK;
 }
 
