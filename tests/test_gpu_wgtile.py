@@ -498,10 +498,9 @@ def test_tall_tiles_whole_image_per_tile(pkg, oracle):
 
 def test_recommended_batch(pkg):
     """deff_recommended_batch: one slot per CU for images that are one tall tile, cell budgets otherwise."""
-    import torch
-    cus = torch.cuda.get_device_properties(0).multi_processor_count
-    assert pkg.recommended_batch(128, 128, 100000) == cus // 8 * 8
-    assert pkg.recommended_batch(127, 200, 100000) == cus // 8 * 8
+    per_cu = pkg.recommended_batch(128, 128, 100000)             # the CU count, rounded down to whole XCD rounds (256 on an MI355X)
+    assert per_cu % 8 == 0 and 8 <= per_cu <= 1024
+    assert pkg.recommended_batch(127, 200, 100000) == per_cu
     assert pkg.recommended_batch(128, 128, 10) == 10
     assert pkg.recommended_batch(128, 225, 100000) == (64 << 20) // (128 * 225)       # too tall for one tile: streaming stacks
     assert pkg.recommended_batch(1024, 1024, 1024) == 64
@@ -514,6 +513,7 @@ def test_recommended_batch(pkg):
         s.sweeps(64)
         p = s.plan()
         assert (p["tb_NW"], p["tb_R"], p["tb_resident"], p["tb_chunks_per_image"]) == (16, 8, 1, 1), p
+        assert p["tb_blocks"] == per_cu                             # one image, one tile, one workgroup, one CU
 
 
 def test_tall_tiles_symmetric_shortcut_is_verified_not_assumed(pkg, oracle):
