@@ -422,10 +422,13 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
                 c->n * sizeof(double) < ((size_t)1 << 31)) {
                 for (int R : WGL_ROWS) {
                     if (c->tb_NW == WGL_WAVES && wgl_has_R(c->tb_R) && R != c->tb_R) continue;
-                    const long tiles = (long)pl->ntx * wgl_row_tiles(own_h, R, T) * c->nimg;
+                    const int row_tiles = wgl_row_tiles(own_h, R, T);
+                    const long tiles = (long)pl->ntx * row_tiles * c->nimg;
                     int res = 0;
                     TRY(wgl_resident_blocks(c, R, pl->fma, c->lut_guard, &res));
-                    if (((tiles + 7) / 8) * 8 <= res) { tall_R = R; break; }
+                    // images that are ONE tile each wait for nobody: any number of them may queue for the CUs
+                    const bool whole_images = pl->ntx == 1 && row_tiles == 1;
+                    if (((tiles + 7) / 8) * 8 <= res || whole_images) { tall_R = R; break; }
                 }
             }
             // a context just above the 4 Mi cells where the streaming form takes over still runs faster on tall tiles

@@ -116,7 +116,16 @@ def test_launch_plan_is_reported(pkg):
         s.init_linear(0.0, 1.0)
         s.sweeps(16)
         p = s.plan()
-        assert p["tb_impl"] == 1 and p["tb_strips"] == 1 and p["tb_LY"] * p["tb_chunks_per_image"] >= 128   # 8 Mi cells: streaming
+        # 512 images of 128^2: each is ONE tall tile (16 waves x 8 rows) that waits for nobody -- resident, whatever their number
+        assert (p["tb_impl"], p["tb_NW"], p["tb_R"], p["tb_resident"]) == (2, 16, 8, 1), p
+        assert p["tb_strips"] == 1 and p["tb_chunks_per_image"] == 1 and p["tb_LY"] == 128 and p["tb_blocks"] == 512
+    with pkg.Solver(512, 512, nimg=32) as s:
+        s.synth_image(1, 0)
+        s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(16)
+        p = s.plan()
+        assert p["tb_impl"] == 1 and p["tb_strips"] == 5 and p["tb_LY"] * p["tb_chunks_per_image"] >= 512   # 8 Mi cells: streaming
     with pkg.Solver(1024, 1024) as s:
         s.synth_image(1, 0)
         s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)

@@ -573,3 +573,37 @@ def test_tall_tiles_symmetric_shortcut_is_verified_not_assumed(pkg, oracle):
         s.sweeps(27)
         assert s.plan()["tb_sym"] == 2
         assert_field(s.get_field(), want3)
+
+
+def test_tall_tiles_whole_images_beyond_one_per_cu(pkg, oracle):
+    """Images that are one tall tile each wait for nobody, so a stack may hold more of them than the chip has CUs (the
+    workgroups queue for the CUs): 260 images of 64 x 48, solved to their own stopping rules -- same iteration counts, Deff
+    and fields as the streaming kernel, three of them against the oracle."""
+    nx, ny, B = 64, 48, 260
+    rng = np.random.default_rng(2600)
+    pixs = np.stack([rand_mask(rng, nx, ny, 0.3 + 0.4 * rng.random()) for _ in range(B)])
+    out = {}
+    for form in ("tall", "streaming"):
+        with pkg.Solver(nx, ny, nimg=B, kernel="matfree_tb") as s:
+            if form == "streaming":
+                s.set_tuning("tb_impl", 1)
+            s.set_image(pixs)
+            s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+            s.init_linear(0.0, 1.0)
+            res = s.solve(1e-3, 4000, check_every=100)
+            p = s.plan()
+            if form == "tall":
+                assert (p["tb_impl"], p["tb_NW"], p["tb_resident"], p["tb_strips"], p["tb_chunks_per_image"]) == (2, 16, 1, 1, 1), p
+                assert p["tb_blocks"] == 264
+            else:
+                assert p["tb_impl"] == 1
+            out[form] = ([(r.iters, r.deff_raw, r.conv) for r in res], s.get_field())
+    assert out["tall"][0] == out["streaming"][0]
+    assert np.array_equal(out["tall"][1], out["streaming"][1])
+    assert len({t[0] for t in out["tall"][0]}) > 3
+    for k in (0, 131, 259):
+        D = oracle.fill_D_2phase(pixs[k], 1.0, 1e-2)
+        A, b = oracle.discretize(D, 0.0, 1.0)
+        it, deff, conv, x, _, _ = oracle.jacobi(A, b, oracle.linear_guess(nx, ny, 0.0, 1.0), D, 0.0, 1.0, 1e-3, 4000, check_every=100)
+        assert out["tall"][0][k] == (it, deff, conv)
+        assert_field(out["tall"][1][k * ny:(k + 1) * ny], x)
