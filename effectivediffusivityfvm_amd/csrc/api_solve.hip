@@ -376,6 +376,220 @@ static int check_links_symmetric(deff_ctx *c)
     return DEFF_OK;
 }
 
+// ---- the plan of a temporally blocked pass (T sweeps), piece by piece ------------------------------------------------
+
+// Strips of 128 columns overlapping by 2*HW; a mesh wall needs no halo (kernels_tb.hpp).
+// Placement A: every strip carries its halo, also outside the first column; placement B: no halo outside a wall.  B needs
+// fewer strips for narrow images (a 128-column image is ONE strip: 2x on dataset batches); where the counts tie, A measured
+// equal or up to 5 % faster in one process (T = 8 at 4096^2), so B is used only when it wins.
+static void plan_strips(const deff_ctx *c, int T, SweepPlan *pl)
+{
+    const int hw = (T + 1) & ~1, wout = TB_COLS - 2 * hw;
+    const int ntx_a = (c->nx + wout - 1) / wout;
+    const int ntx_b = c->nx <= TB_COLS ? 1 : (c->nx - TB_COLS + wout - 1) / wout + 1;
+    const bool use_b = c->tb_wall_halo == 0 ? true : (c->tb_wall_halo == 1 ? false : ntx_b < ntx_a);
+    pl->shift = use_b ? 0 : hw;
+    pl->ntx = use_b ? ntx_b : ntx_a;
+}
+
+// flags (one 256-byte block per tile) and the abort word of the resident launches
+static int ensure_resident_buffers(deff_ctx *c, long tiles)
+{
+    if (c->res_flags_n < (size_t)tiles) {
+        if (c->res_flags) { HIP_TRY(hipFree(c->res_flags)); c->res_flags = nullptr; }
+        TRY(dev_alloc(&c->res_flags, (size_t)tiles * WGR_FLAG_STRIDE));
+        HIP_TRY(hipMemsetAsync(c->res_flags, 0, sizeof(unsigned) * tiles * WGR_FLAG_STRIDE, c->stream));
+        c->res_flags_n = (size_t)tiles;
+    }
+    if (!c->res_abort) {
+        TRY(dev_alloc(&c->res_abort, 1));
+        HIP_TRY(hipMemsetAsync(c->res_abort, 0, sizeof(unsigned), c->stream));
+    }
+    if (c->coop_launch < 0)
+        HIP_TRY(hipDeviceGetAttribute(&c->coop_launch, hipDeviceAttributeCooperativeLaunch, c->device));
+    return DEFF_OK;
+}
+
+// Can this plan run resident at all?  A whole context (a slab's halo rows change between passes from outside), not a band
+// of one, 32-bit buffer offsets, and the caller has not asked for one launch per pass.
+static bool resident_allowed(const deff_ctx *c, const SweepPlan *pl)
+{
+    return c->tb_resident && !c->slab && pl->band_h <= 0 && !pl->T_override && c->n * sizeof(double) < ((size_t)1 << 31);
+}
+
+// Tall resident tiles (16 waves x R rows, kernels_wgtile.hpp): the smallest R in WGL_ROWS whose tiles all fit the chip -- or
+// whose tiles are whole images, which wait for nobody and may queue for the CUs in any number --, or 0.  T = 8 only; not when
+// the caller shapes the 8-wave tiles (tb_R, tb_LY) or insists on them (tb_NW = 8).
+static int choose_tall_R(const deff_ctx *c, const SweepPlan *pl, int T, int own_h, int *tall_R)
+{
+    *tall_R = 0;
+    if (T != 8 || !resident_allowed(c, pl) || c->tb_NW == WGT_WAVES) return DEFF_OK;
+    if (c->tb_NW != WGL_WAVES && (c->tb_R != 0 || c->tb_LY != 0)) return DEFF_OK;
+    for (int R : WGL_ROWS) {
+        if (c->tb_NW == WGL_WAVES && wgl_has_R(c->tb_R) && R != c->tb_R) continue;
+        const int row_tiles = wgl_row_tiles(own_h, R, T);
+        const long tiles = (long)pl->ntx * row_tiles * c->nimg;
+        int res = 0;
+        TRY(wgl_resident_blocks(c, R, pl->fma, c->lut_guard, &res));
+        const bool whole_images = pl->ntx == 1 && row_tiles == 1;
+        if (((tiles + 7) / 8) * 8 <= res || whole_images) { *tall_R = R; break; }
+    }
+    return DEFF_OK;
+}
+
+// 8-wave tiles (matrix rows in registers): rows per wave, rows per tile, grid; resident when all tiles fit the chip.
+static int plan_tiles8(deff_ctx *c, SweepPlan *pl, int T, int own_h)
+{
+    pl->impl = 2;
+    pl->NW = WGT_WAVES;
+    pl->guard = c->lut_guard;
+    int resident = c->tb_wg;
+    if (c->tb_R == 4 || c->tb_R == 6 || c->tb_R == 7) {
+        pl->R = c->tb_R;
+    } else {
+        // rows per wave: the fewest (shortest sweeps) whose tiles are all resident at once; if none is, 6
+        // (7 needs 256 VGPRs and a few spilled registers: fine for one round, slower over several)
+        pl->R = 6;
+        for (int R : {4, 6, 7}) {
+            const int lymax = wgt_rows_owned(T, R);
+            if (lymax < 1) continue;
+            int res = resident;
+            if (!res) TRY(wgt_resident_blocks(c, T, R, pl->fma, c->lut_guard, &res));
+            const long tiles = (long)pl->ntx * ((own_h + lymax - 1) / lymax) * c->nimg;
+            if (tiles <= res) { pl->R = R; break; }
+        }
+    }
+    // rows a tile owns: at most 8R - 2T; spread the image's rows evenly over its row tiles
+    const int lymax = wgt_rows_owned(T, pl->R);
+    int cpi = (own_h + lymax - 1) / lymax;
+    if (c->tb_LY > 0 && c->tb_LY < lymax) cpi = (own_h + c->tb_LY - 1) / c->tb_LY;
+    pl->LY = (own_h + cpi - 1) / cpi;
+    pl->tcpi = (own_h + pl->LY - 1) / pl->LY;
+    pl->tgy = pl->tcpi * c->nimg;
+    const long tiles = (long)pl->ntx * pl->tgy;
+    if (!resident) TRY(wgt_resident_blocks(c, T, pl->R, pl->fma, c->lut_guard, &resident));
+    pl->tgx = (int)tiles;
+    pl->tblocks = (int)(((tiles + 7) / 8) * 8);
+    if (pl->tblocks > resident) pl->tblocks = resident >= 8 ? resident / 8 * 8 : 8;
+    // Resident passes (k_sweep_wgres): every tile on the chip at once, tiles at least T rows tall (a tile's halo must end
+    // inside its immediate neighbours: they are the ones it waits for)
+    pl->resident = false;
+    if (resident_allowed(c, pl) && (pl->LY >= T || pl->tcpi == 1)) {
+        int res = 0;
+        TRY(wgr_resident_blocks(c, T, pl->R, pl->fma, c->lut_guard, &res));
+        if ((long)((tiles + 7) / 8) * 8 <= res) {
+            pl->resident = true;
+            pl->tblocks = (int)(((tiles + 7) / 8) * 8);
+            TRY(ensure_resident_buffers(c, tiles));
+        }
+    }
+    return DEFF_OK;
+}
+
+// Tall tiles with R rows per wave: always resident; the 7-lookup short-cut when the system is verified link-symmetric.
+static int plan_tall(deff_ctx *c, SweepPlan *pl, int T, int own_h, int R)
+{
+    pl->impl = 2;
+    pl->NW = WGL_WAVES;
+    pl->R = R;
+    pl->guard = c->lut_guard;
+    const int cpi = wgl_row_tiles(own_h, R, T);
+    pl->LY = (own_h + cpi - 1) / cpi;
+    pl->tcpi = (own_h + pl->LY - 1) / pl->LY;
+    pl->tgy = pl->tcpi * c->nimg;
+    const long tiles = (long)pl->ntx * pl->tgy;
+    pl->tgx = (int)tiles;
+    pl->tblocks = (int)(((tiles + 7) / 8) * 8);
+    pl->resident = true;
+    TRY(ensure_resident_buffers(c, tiles));
+    if (c->tb_sym != 2) TRY(check_links_symmetric(c));            // once per (codes, dictionary): one pass over the codes
+    pl->sym = c->tb_sym != 2 && c->links_sym == 1;
+    return DEFF_OK;
+}
+
+// Streaming form: rows per chunk.  Workgroups are persistent, so a pass takes `rounds` tiles per wave slot (one round = as
+// many wave tiles as are resident at once), and a tile costs its LY rows + T steps that drain the pipeline + T rows of halo
+// above it unless it starts at the top wall of its image + a fixed start-up (first loads, measured ~8 row steps).  Pick the
+// chunks per image minimising rounds x tile cost; for k rounds only the largest chunk count that fits matters.  (Stacks of
+// small images: 3 072 x 128^2 as whole-image tiles 1 266 G cells*iter/s against 1 107 G for the 4 x 32-row tiles a
+// halo-blind model picks.)
+static int plan_streaming(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int own_h)
+{
+    pl->impl = 1;
+    pl->resident = false;
+    pl->guard = c->lut_guard;                          // the reference's non-zero link test matters only when a phase cannot diffuse
+    int resident = c->tb_wg;
+    if (!resident) TRY(tb_resident_blocks(c, T, pl->fma, c->lut_guard, &resident));
+    int LY = c->tb_LY;
+    if (!LY) {
+        long best_cost = -1;
+        const bool top_wall = own_lo == 0;              // not a slab with rows above it
+        for (int k = 1; k <= 8; ++k) {
+            const int cpi_max = (int)(((long)k * resident * 4) / ((long)pl->ntx * c->nimg));
+            if (cpi_max < 1) continue;
+            int ly = (own_h + cpi_max - 1) / cpi_max;
+            // chunks shorter than the pipeline is deep lose more to fill/drain than the model says (1024^2, T=4: 3-row
+            // chunks 254 G, 4..6-row chunks 295 G cells*iter/s)
+            if (ly < T) ly = T;
+            const int cpi = (own_h + ly - 1) / ly;
+            const long cost = (long)k * (ly + T + ((cpi > 1 || !top_wall) ? T : 0) + 8);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; LY = ly; }
+        }
+        if (!LY) LY = own_h;
+    }
+    if (LY > own_h) LY = own_h;
+    pl->LY = LY;
+    pl->tcpi = (own_h + LY - 1) / LY;
+    pl->tgy = pl->tcpi * c->nimg;
+    pl->tgx = (int)(((long)pl->ntx * pl->tgy + 3) / 4);           // workgroup tiles (4 wave tiles each)
+    const unsigned total = (unsigned)pl->tgx;
+    pl->tblocks = (int)(((total + 7u) / 8u) * 8u);
+    if (pl->tblocks > resident) pl->tblocks = resident >= 8 ? resident / 8 * 8 : 8;
+    return DEFF_OK;
+}
+
+// what deff_get_plan() reports: the plan of whole passes of the context (not a slab's T = 1 remainder plan, not a band)
+static void record_plan(deff_ctx *c, const SweepPlan *pl)
+{
+    if (pl->band_h > 0 || (pl->impl == 1 && pl->T_override)) return;
+    c->plan_T = pl->T; c->plan_LY = pl->LY; c->plan_ntx = pl->ntx; c->plan_cpi = pl->tcpi;
+    c->plan_blocks = pl->tblocks; c->plan_impl = pl->impl;
+    c->plan_R = pl->impl == 2 ? pl->R : 0;
+    c->plan_NW = pl->impl == 2 ? pl->NW : 0;
+    c->plan_resident = pl->impl == 2 && pl->resident ? 1 : 0;
+}
+
+// The form of a blocked pass, in this order ("What the planner picks"): 8-wave tiles when they are all
+// resident; tall tiles when those are; else 8-wave tiles with one launch per pass below 4 Mi cells and streaming above.
+static int plan_blocked_pass(deff_ctx *c, SweepPlan *pl)
+{
+    // sweeps per pass (measured, G cells*iter/s: 4096^2 T=4 926, T=6 1063, T=8 1106; stacks of 16 x 1024^2 peak at T=6;
+    // 1024^2 alone at T=4)
+    const int T = clamp_tb_T(pl->T_override ? pl->T_override : (c->tb_T ? c->tb_T : default_tb_T(c)));
+    pl->T = T;
+    // rows this plan updates: the context's owned rows, or a band of them (row slabs split a pass into the bands the
+    // neighbours wait for and the interior, api_slab.hip)
+    const int own_lo = pl->band_h > 0 ? pl->band_lo : c->own_lo;
+    const int own_h = pl->band_h > 0 ? pl->band_h : c->own_h;
+    pl->own_lo = own_lo;
+    pl->own_h = own_h;
+    plan_strips(c, T, pl);
+    int tall_R = 0;
+    TRY(choose_tall_R(c, pl, T, own_h, &tall_R));
+    int want_impl = c->tb_impl ? c->tb_impl : default_tb_impl(c);
+    // a context just above the 4 Mi cells where the streaming form takes over still runs faster on tall tiles when they fit
+    if (!c->tb_impl && want_impl == 1 && tall_R) want_impl = 2;
+    // workgroup tiles exist for T = 4 and 8; slabs' T = 1 remainder passes and the other T stay on the streaming kernel
+    if (want_impl == 2 && (T == 4 || T == 8) && !pl->T_override) {
+        TRY(plan_tiles8(c, pl, T, own_h));
+        if (tall_R && (!pl->resident || c->tb_NW == WGL_WAVES)) TRY(plan_tall(c, pl, T, own_h, tall_R));
+    } else {
+        TRY(plan_streaming(c, pl, T, own_lo, own_h));
+    }
+    record_plan(c, pl);
+    return DEFF_OK;
+}
+
 int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
 {
     if (!c->have_field) return fail(DEFF_ESTATE, "no field: call deff_init_linear() or deff_set_field()");
@@ -388,189 +602,10 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
     pl->omw = 1.0 - omega;                              // cuh:89 evaluates (1.0 - w) in double
     if (pl->kernel == DEFF_KERNEL_MATFREE || pl->kernel == DEFF_KERNEL_MATFREE_TB) {
         TRY(upload_lut(c, omega));
-        if (pl->kernel == DEFF_KERNEL_MATFREE_TB) {
-            // sweeps per pass (measured, G cells*iter/s: 4096^2 T=4 926, T=6 1063, T=8 1106; stacks of
-            // 16 x 1024^2 peak at T=6; 1024^2 alone at T=4)
-            int T = pl->T_override ? pl->T_override : (c->tb_T ? c->tb_T : default_tb_T(c));
-            T = clamp_tb_T(T);
-            pl->T = T;
-            // rows this plan updates: the context's owned rows, or a band of them (row slabs split a pass into the
-            // bands the neighbours wait for and the interior, api_slab.hip)
-            const int own_lo = pl->band_h > 0 ? pl->band_lo : c->own_lo;
-            const int own_h = pl->band_h > 0 ? pl->band_h : c->own_h;
-            pl->own_lo = own_lo;
-            pl->own_h = own_h;
-            // strips of 128 columns overlapping by 2*HW; a mesh wall needs no halo (kernels_tb.hpp)
-            const int hw = (T + 1) & ~1, wout = TB_COLS - 2 * hw;
-            // placement A: every strip carries its halo, also outside the first column; placement B:
-            // no halo outside a wall (kernels_tb.hpp).  B needs fewer strips for narrow images
-            // (a 128-column image is ONE strip: 2x on dataset batches); where the counts tie, A measured
-            // equal or up to 5 % faster in one process (T = 8 at 4096^2), so B is used only when it wins.
-            const int ntx_a = (c->nx + wout - 1) / wout;
-            const int ntx_b = c->nx <= TB_COLS ? 1 : (c->nx - TB_COLS + wout - 1) / wout + 1;
-            const bool use_b = c->tb_wall_halo == 0 ? true : (c->tb_wall_halo == 1 ? false : ntx_b < ntx_a);
-            pl->shift = use_b ? 0 : hw;
-            pl->ntx = use_b ? ntx_b : ntx_a;
-            // Form of the pass.  Workgroup tiles exist for T = 4 and 8; slabs' T = 1 remainder passes and the other
-            // T stay on the streaming kernel.
-            int want_impl = c->tb_impl ? c->tb_impl : default_tb_impl(c);
-            // Tall resident tiles (16 waves x R rows, kernels_wgtile.hpp): the smallest R in WGL_ROWS whose tiles all fit
-            // the chip, or 0.  They only exist resident, for T = 8, on whole contexts.
-            int tall_R = 0;
-            if (T == 8 && !pl->T_override && c->tb_resident && !c->slab && pl->band_h <= 0 && c->tb_NW != WGT_WAVES &&
-                (c->tb_NW == WGL_WAVES || (c->tb_R == 0 && c->tb_LY == 0)) &&      // not when the caller shapes the 8-wave tiles
-                c->n * sizeof(double) < ((size_t)1 << 31)) {
-                for (int R : WGL_ROWS) {
-                    if (c->tb_NW == WGL_WAVES && wgl_has_R(c->tb_R) && R != c->tb_R) continue;
-                    const int row_tiles = wgl_row_tiles(own_h, R, T);
-                    const long tiles = (long)pl->ntx * row_tiles * c->nimg;
-                    int res = 0;
-                    TRY(wgl_resident_blocks(c, R, pl->fma, c->lut_guard, &res));
-                    // images that are ONE tile each wait for nobody: any number of them may queue for the CUs
-                    const bool whole_images = pl->ntx == 1 && row_tiles == 1;
-                    if (((tiles + 7) / 8) * 8 <= res || whole_images) { tall_R = R; break; }
-                }
-            }
-            // a context just above the 4 Mi cells where the streaming form takes over still runs faster on tall tiles
-            // when they fit (2048^2: 228 tiles of 192 rows)
-            if (!c->tb_impl && want_impl == 1 && tall_R) want_impl = 2;
-            if (want_impl == 2 && (T == 4 || T == 8) && !pl->T_override) {
-                pl->impl = 2;
-                int resident = c->tb_wg;
-                if (c->tb_R == 4 || c->tb_R == 6 || c->tb_R == 7) {
-                    pl->R = c->tb_R;
-                } else {
-                    // rows per wave: the fewest (shortest sweeps) whose tiles are all resident at once; if none is, 6
-                    // (7 needs 256 VGPRs and a few spilled registers: fine for one round, slower over several)
-                    pl->R = 6;
-                    for (int R : {4, 6, 7}) {
-                        const int lymax = wgt_rows_owned(T, R);
-                        if (lymax < 1) continue;
-                        int res = resident;
-                        if (!res) TRY(wgt_resident_blocks(c, T, R, pl->fma, c->lut_guard, &res));
-                        const long tiles = (long)pl->ntx * ((own_h + lymax - 1) / lymax) * c->nimg;
-                        if (tiles <= res) { pl->R = R; break; }
-                    }
-                }
-                pl->NW = WGT_WAVES;
-                const int lymax = wgt_rows_owned(T, pl->R);
-                // rows a tile owns: at most 8R - 2T; spread the image's rows evenly over its row tiles
-                int cpi = (own_h + lymax - 1) / lymax;
-                if (c->tb_LY > 0 && c->tb_LY < lymax) cpi = (own_h + c->tb_LY - 1) / c->tb_LY;
-                pl->LY = (own_h + cpi - 1) / cpi;
-                pl->tcpi = (own_h + pl->LY - 1) / pl->LY;
-                pl->tgy = pl->tcpi * c->nimg;
-                const long tiles = (long)pl->ntx * pl->tgy;
-                if (!resident) TRY(wgt_resident_blocks(c, T, pl->R, pl->fma, c->lut_guard, &resident));
-                pl->tgx = (int)tiles;
-                pl->tblocks = (int)(((tiles + 7) / 8) * 8);
-                if (pl->tblocks > resident) pl->tblocks = resident >= 8 ? resident / 8 * 8 : 8;
-                pl->guard = c->lut_guard;
-                // Resident passes (k_sweep_wgres): every tile on the chip at once, a whole context (no slab, whose halo
-                // rows change between passes from outside), tiles at least T rows tall (a tile's halo must end inside its
-                // immediate neighbours: they are the ones it waits for), no per-tile diagnostics.
-                pl->resident = false;
-                if (c->tb_resident && !c->slab && pl->band_h <= 0 &&
-                    (pl->LY >= T || pl->tcpi == 1) &&
-                    c->n * sizeof(double) < ((size_t)1 << 31)) {      // 32-bit buffer offsets
-                    int res = 0;
-                    TRY(wgr_resident_blocks(c, T, pl->R, pl->fma, c->lut_guard, &res));
-                    if (c->coop_launch < 0)
-                        HIP_TRY(hipDeviceGetAttribute(&c->coop_launch, hipDeviceAttributeCooperativeLaunch, c->device));
-                    if ((long)((tiles + 7) / 8) * 8 <= res) {
-                        pl->resident = true;
-                        pl->tblocks = (int)(((tiles + 7) / 8) * 8);
-                        if (c->res_flags_n < (size_t)tiles) {
-                            if (c->res_flags) { HIP_TRY(hipFree(c->res_flags)); c->res_flags = nullptr; }
-                            TRY(dev_alloc(&c->res_flags, (size_t)tiles * WGR_FLAG_STRIDE));
-                            HIP_TRY(hipMemsetAsync(c->res_flags, 0, sizeof(unsigned) * tiles * WGR_FLAG_STRIDE, c->stream));
-                            c->res_flags_n = (size_t)tiles;
-                        }
-                        if (!c->res_abort) {
-                            TRY(dev_alloc(&c->res_abort, 1));
-                            HIP_TRY(hipMemsetAsync(c->res_abort, 0, sizeof(unsigned), c->stream));
-                        }
-                    }
-                }
-                if (tall_R && (!pl->resident || c->tb_NW == WGL_WAVES)) {
-                    pl->R = tall_R;
-                    pl->NW = WGL_WAVES;
-                    const int cpiL = wgl_row_tiles(own_h, tall_R, T);
-                    pl->LY = (own_h + cpiL - 1) / cpiL;
-                    pl->tcpi = (own_h + pl->LY - 1) / pl->LY;
-                    pl->tgy = pl->tcpi * c->nimg;
-                    const long tilesL = (long)pl->ntx * pl->tgy;
-                    pl->tgx = (int)tilesL;
-                    pl->tblocks = (int)(((tilesL + 7) / 8) * 8);
-                    pl->resident = true;
-                    if (c->res_flags_n < (size_t)tilesL) {
-                        if (c->res_flags) { HIP_TRY(hipFree(c->res_flags)); c->res_flags = nullptr; }
-                        TRY(dev_alloc(&c->res_flags, (size_t)tilesL * WGR_FLAG_STRIDE));
-                        HIP_TRY(hipMemsetAsync(c->res_flags, 0, sizeof(unsigned) * tilesL * WGR_FLAG_STRIDE, c->stream));
-                        c->res_flags_n = (size_t)tilesL;
-                    }
-                    if (!c->res_abort) {
-                        TRY(dev_alloc(&c->res_abort, 1));
-                        HIP_TRY(hipMemsetAsync(c->res_abort, 0, sizeof(unsigned), c->stream));
-                    }
-                    if (c->coop_launch < 0)
-                        HIP_TRY(hipDeviceGetAttribute(&c->coop_launch, hipDeviceAttributeCooperativeLaunch, c->device));
-                    // link symmetry of the system, looked at once per (codes, dictionary): one pass over the codes
-                    if (c->tb_sym != 2) TRY(check_links_symmetric(c));
-                    pl->sym = c->tb_sym != 2 && c->links_sym == 1;
-                }
-                if (pl->band_h <= 0) {
-                    c->plan_T = pl->T; c->plan_LY = pl->LY; c->plan_ntx = pl->ntx; c->plan_cpi = pl->tcpi;
-                    c->plan_blocks = pl->tblocks; c->plan_impl = 2; c->plan_R = pl->R; c->plan_NW = pl->NW;
-                    c->plan_resident = pl->resident ? 1 : 0;
-                }
-            } else {
-            pl->impl = 1;
-            // Rows per chunk.  Workgroups are persistent, so a pass takes `rounds` tiles per wave slot
-            // (one round = as many wave tiles as are resident at once), and a tile costs its LY rows
-            // + T steps that drain the pipeline + T rows of halo above it unless it starts at the top
-            // wall of its image + a fixed start-up (first loads, measured ~8 row steps).  Pick the
-            // chunks per image minimising rounds x tile cost; for k rounds only the largest chunk
-            // count that fits matters.  (Stacks of small images: 3 072 x 128^2 as whole-image tiles
-            // 1 266 G cells*iter/s against 1 107 G for the 4 x 32-row tiles a halo-blind model picks.)
-            int resident = c->tb_wg;
-            if (!resident) TRY(tb_resident_blocks(c, T, pl->fma, c->lut_guard, &resident));
-            int LY = c->tb_LY;
-            if (!LY) {
-                long best_cost = -1;
-                const bool top_wall = own_lo == 0;              // not a slab with rows above it
-                for (int k = 1; k <= 8; ++k) {
-                    const int cpi_max = (int)(((long)k * resident * 4) / ((long)pl->ntx * c->nimg));
-                    if (cpi_max < 1) continue;
-                    int ly = (own_h + cpi_max - 1) / cpi_max;
-                    // chunks shorter than the pipeline is deep lose more to fill/drain than the model
-                    // says (1024^2, T=4: 3-row chunks 254 G, 4..6-row chunks 295 G cells*iter/s)
-                    if (ly < T) ly = T;
-                    const int cpi = (own_h + ly - 1) / ly;
-                    const long cost = (long)k * (ly + T + ((cpi > 1 || !top_wall) ? T : 0) + 8);
-                    if (best_cost < 0 || cost < best_cost) { best_cost = cost; LY = ly; }
-                }
-                if (!LY) LY = own_h;
-            }
-            if (LY > own_h) LY = own_h;
-            pl->LY = LY;
-            pl->tcpi = (own_h + LY - 1) / LY;
-            pl->tgy = pl->tcpi * c->nimg;
-            pl->tgx = (int)(((long)pl->ntx * pl->tgy + 3) / 4);       // workgroup tiles (4 wave tiles each)
-            const unsigned total = (unsigned)pl->tgx;
-            pl->tblocks = (int)(((total + 7u) / 8u) * 8u);
-            if (pl->tblocks > resident) pl->tblocks = resident >= 8 ? resident / 8 * 8 : 8;
-            if (!pl->T_override && pl->band_h <= 0) {    // the remainder plan of a slab (T = 1) and band plans are not "the" plan
-                c->plan_T = pl->T; c->plan_LY = pl->LY; c->plan_ntx = pl->ntx; c->plan_cpi = pl->tcpi;
-                c->plan_blocks = pl->tblocks; c->plan_impl = 1; c->plan_R = 0; c->plan_resident = 0;
-            }
-            // the reference's non-zero link test matters only when a phase cannot diffuse
-            pl->guard = c->lut_guard;
-            }
-        }
-        // 4 rows per tile and up to 8 192 workgroups (measured at 4096^2: 52.0 us = 5.8 TB/s against 59-61 us for 8 rows x
-        // 2 048 persistent workgroups; 16384^2: 960-990 us = 4.9-5.0 TB/s either way -- above what a plain copy kernel gets
-        // from HBM for this read / write mix, tools/ubench mem: 4.7 TB/s)
+        if (pl->kernel == DEFF_KERNEL_MATFREE_TB) TRY(plan_blocked_pass(c, pl));
+        // single sweeps (the first sweep and the n mod T remainder): 4 rows per tile and up to 8 192 workgroups (measured at
+        // 4096^2: 52.0 us = 5.8 TB/s against 59-61 us for 8 rows x 2 048 persistent workgroups; 16384^2: 960-990 us = 4.9-5.0
+        // TB/s either way -- above what a plain copy kernel gets from HBM for this read / write mix, tools/ubench mem: 4.7 TB/s)
         tile_grid(c, 256 * 2, pick_R(c->rows_matfree, c->n >= ((size_t)1 << 21) ? 4 : 2), pl);
         // persistent grid: workgroups walk the tiles (tables loaded once each)
         const int cap = c->wg_matfree ? c->wg_matfree : 256 * 32;
