@@ -84,6 +84,70 @@ def live_traffic(n, kernel, kernel_used):
     return got["FETCH_SIZE"] * 2.0 + got["WRITE_SIZE"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child runs of this command (x2 read correction, gfx950)"
 
 
+def live_kernel_stats(n, kernel, kernel_used, steps, warmup, sweeps_per_step, omega):
+    """Average duration of the dominant sweep kernel as rocprofv3 sees it, measured NOW on this box: one child run of this
+    script's timed region (`--primary-only`, same --steps / --warmup / --sweeps-per-step) under `rocprofv3 --kernel-trace
+    --stats` (the program itself after `--`).  The summary it parses is also left in gpurun_out/ (copied to profiles/ per
+    round), so that roofline.frac can be recomputed from a profile of the same box.  Returns a dict or None."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    want = {"matfree_tb": "k_sweep_matfree_tb", "matfree": "k_sweep_matfree<", "explicit": "k_sweep_explicit",
+            "scalar": "k_sweep_scalar"}.get(kernel_used)
+    if not os.path.exists(exe) or want is None:
+        return None
+    env = dict(os.environ, TMPDIR="/tmp")
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "--", sys.executable,
+               os.path.abspath(__file__), "--size", str(n), "--kernel", kernel, "--steps", str(steps), "--warmup", str(warmup),
+               "--sweeps-per-step", str(sweeps_per_step), "--omega", repr(omega), "--primary-only"]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            files = glob.glob(os.path.join(tmp, "*", "*_kernel_stats.csv"))
+            if r.returncode != 0 or not files:
+                return None
+            f = max(files, key=os.path.getmtime)
+            rows = [row for row in csv.DictReader(open(f)) if want in row["Name"]]
+            if not rows:
+                return None
+            top = max(rows, key=lambda row: float(row["TotalDurationNs"]))
+            keep = os.path.join(ROOT, "gpurun_out")
+            if os.path.isdir(keep) and os.access(keep, os.W_OK):
+                shutil.copyfile(f, os.path.join(keep, "bench_live_kernel_stats.csv"))
+            child = None
+            for line in r.stdout.splitlines():
+                if line.startswith("{") and '"metric"' in line:
+                    child = json.loads(line)
+            return {"rocprof_avg_us": float(top["AverageNs"]) / 1e3, "rocprof_min_us": float(top["MinNs"]) / 1e3,
+                    "rocprof_calls": int(top["Calls"]), "rocprof_share_of_gpu_time_pct": float(top["Percentage"]),
+                    "rocprof_kernel": top["Name"].split("(")[0],
+                    "rocprof_child_launch_us": child["roofline"]["launch_us"] if child else None,
+                    "rocprof_source": "rocprofv3 --kernel-trace --stats, one child run of this command's timed region "
+                                      "(--primary-only) on this box; summary kept as gpurun_out/bench_live_kernel_stats.csv"}
+        except Exception:
+            return None
+
+
+def iters_to_tol_1024(pkg, device, kernel):
+    """The second half of BASELINE.json's metric, on config #2: ONE 1024^2 synthetic image (seed 12345, image 0, Ds 1e-3)
+    by the reference's rule (relative Deff change per 10 000 sweeps < 1e-6, JacobiGPU cuh:1232-1290) through deff_solve."""
+    with pkg.Solver(1024, 1024, device=device, kernel=kernel) as s:
+        s.synth_image(12345, 0)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        t0 = time.perf_counter()
+        r = s.solve(1e-6, 30_000_000)
+        dt = time.perf_counter() - t0
+        return {"iters": int(r.iters), "checks": int(r.checks), "deff": r.deff_raw, "conv": r.conv, "seconds": dt,
+                "loop_ms": r.loop_ms, "Mcells_iter_per_s": 1024.0 * 1024.0 * r.iters / dt / 1e6, "tol": 1e-6,
+                "plan": s.plan(),
+                "sample": "ONE 1024x1024 synthetic image (BASELINE config #2) from the linear guess to the reference's "
+                          "stopping rule, tol 1e-6, check every 10 000 sweeps, wall time of deff_solve() incl. all checks"}
+
+
 def cpu_baseline(n, seconds_target=12.0):
     """Single-thread oracle sweep rate on the same synthetic workload (bounded sample).
     Returns (block, sweeps, field): the field after `sweeps` sweeps from the linear guess is kept so that
@@ -217,6 +281,8 @@ def main():
                                                                    "measuring it now (two rocprofv3 --pmc child runs)")
     ap.add_argument("--no-small-image", action="store_true", help="skip the ONE-1024^2-image row (profiling runs: its "
                                                                   "launches would mix into the per-kernel averages)")
+    ap.add_argument("--no-live-stats", action="store_true", help="skip the rocprofv3 --kernel-trace --stats child run")
+    ap.add_argument("--no-iters-to-tol", action="store_true", help="skip config #2's solve to tolerance (~2.5 s)")
     ap.add_argument("--explicit-sweeps", type=int, default=300,
                     help="sweeps of the secondary explicit-coefficient measurement (0 = skip)")
     ap.add_argument("--tune", action="append", default=[], help="key=value tuning knob (repeatable)")
@@ -228,7 +294,7 @@ def main():
                                                          "(one process, peer copies) and report the exchange's exposed time")
     args = ap.parse_args()
     if args.primary_only:
-        args.no_cpu_baseline = args.no_small_image = args.no_live_traffic = True
+        args.no_cpu_baseline = args.no_small_image = args.no_live_traffic = args.no_live_stats = args.no_iters_to_tol = True
         args.explicit_sweeps = 0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -345,6 +411,10 @@ def main():
             ms3 = min(s3.sweeps(2400, args.omega) for _ in range(3))
             mid = (2048.0 * 2048.0 * 2400 / (ms3 * 1e-3) / 1e6, s3.kernel_in_use(), s3.plan())
 
+    tol1024 = None
+    if rank == 0 and world == 1 and args.batch == 1 and not args.no_iters_to_tol:
+        tol1024 = iters_to_tol_1024(pkg, local_rank, args.kernel)
+
     if rank == 0:
         cells = float(n) * n * args.batch
         total_launches = args.steps * launches
@@ -401,6 +471,12 @@ def main():
         elif tr:
             roofline["traffic"] = tr["hbm_bytes_per_launch"]
             roofline["traffic_source"] = tr.get("source")
+        if world == 1 and args.batch == 1 and not args.no_live_stats:
+            st = live_kernel_stats(n, args.kernel, kernel_used, args.steps, args.warmup, S, args.omega)
+            if st:
+                roofline.update(st)
+                if kernel_used == "matfree_tb":
+                    roofline["rocprof_frac"] = flops / (st["rocprof_avg_us"] * 1e-6) / 1e12 / FP64_INSTR_PEAK_T
         if explicit:
             el, ek = explicit
             ea = BYTES_PER_CELL_SWEEP * cells / el / 1e9
@@ -461,6 +537,8 @@ def main():
             out["single_image_2048"] = {"value": mid[0], "unit": "Mcells*iter/s", "kernel": mid[1], "plan": mid[2],
                                         "fp64_instr_frac": FP64_INSTR_PER_CELL[False] * mid[0] * 1e6 / 1e12 / FP64_INSTR_PEAK_T,
                                         "sample": "2400 sweeps (best of 3) of ONE 2048x2048 synthetic image, same physics, one GPU"}
+        if tol1024:
+            out["iters_to_tol_1024"] = tol1024
         if world == 1 and not args.no_cpu_baseline:
             base, K, want = cpu_baseline(n)
             out["cpu_baseline"] = base

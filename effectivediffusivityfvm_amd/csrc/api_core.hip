@@ -126,6 +126,7 @@ try {
     if (c->q) (void)hipFree(c->q);
     if (c->res_flags) (void)hipFree(c->res_flags);
     if (c->res_abort) (void)hipFree(c->res_abort);
+    if (c->res_backup) (void)hipFree(c->res_backup);
     if (c->q_host) (void)hipHostFree(c->q_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -247,9 +248,9 @@ try {
     else if (!strcmp(key, "tb_R")) c->tb_R = value;
     else if (!strcmp(key, "tb_debug_stall")) c->tb_debug_stall = value;
     else if (!strcmp(key, "tb_sym")) c->tb_sym = value;
-    else if (!strcmp(key, "tb_launch")) {            // 0 / 2: resident passes where possible (2: cooperative launch); 1: one launch per pass
+    else if (!strcmp(key, "tb_launch")) {            // 0: resident passes where possible; 1: one launch per pass
+        if (value > 1) return fail(DEFF_EINVAL, "tb_launch takes 0 (resident passes where the tiles fit the chip) or 1 (one launch per pass)");
         c->tb_resident = value == 1 ? 0 : 1;
-        c->tb_coop = value == 2 ? 1 : 0;
     }
     else if (!strcmp(key, "flux_reduce")) c->flux_reduce = value > 2 ? 0 : value;
     else if (!strcmp(key, "tb_NW")) c->tb_NW = value;
@@ -277,6 +278,7 @@ try {
     else if (!strcmp(key, "tb_resident")) *value = c->plan_resident;
     else if (!strcmp(key, "tb_sym")) *value = c->links_sym;
     else if (!strcmp(key, "tb_NW")) *value = c->plan_NW;
+    else if (!strcmp(key, "tb_fallbacks")) *value = c->res_fallbacks;
     else return fail(DEFF_EINVAL, "unknown plan key '%s'", key);
     return DEFF_OK;
 }

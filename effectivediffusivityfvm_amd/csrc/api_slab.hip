@@ -53,7 +53,9 @@ static int slab_pass_plans(deff_ctx *c, double omega, int T_override, int overla
     sp->whole.T_override = T_override;
     TRY(plan_sweeps(c, omega, &sp->whole));
     if (sp->whole.kernel != DEFF_KERNEL_MATFREE_TB) return fail(DEFF_ESTATE, "row-slab mode needs the temporally blocked kernel");
-    sp->split = (overlap == 2 || (overlap == 1 && c->n >= ((size_t)1 << 24))) && c->own_h >= 3 * SLAB_HALO;
+    // keyed on tb_ref_cells -- a figure of (nx, NY, slab count) alone -- so that every slab / rank of an image splits alike
+    const size_t ref = c->tb_ref_cells ? c->tb_ref_cells : c->n;
+    sp->split = (overlap == 2 || (overlap == 1 && ref >= ((size_t)1 << 24))) && c->own_h >= 3 * SLAB_HALO;
     if (!sp->split) return DEFF_OK;
     const int lo[3] = {c->own_lo, c->own_lo + c->own_h - SLAB_HALO, c->own_lo + SLAB_HALO};
     const int h[3] = {SLAB_HALO, SLAB_HALO, c->own_h - 2 * SLAB_HALO};
@@ -72,13 +74,13 @@ static int slab_pass_plans(deff_ctx *c, double omega, int T_override, int overla
 static int slab_enqueue_pass(deff_ctx *c, const SlabPass &sp, hipEvent_t bnd)
 {
     if (sp.split) {
-        launch_tb_pass(c, sp.top);
-        launch_tb_pass(c, sp.bot);
+        TRY(launch_tb_pass(c, sp.top));
+        TRY(launch_tb_pass(c, sp.bot));
         HIP_TRY(hipEventRecord(bnd, c->stream));
-        launch_tb_pass(c, sp.mid);
+        TRY(launch_tb_pass(c, sp.mid));
         c->last_launches += 3;
     } else {
-        launch_tb_pass(c, sp.whole);
+        TRY(launch_tb_pass(c, sp.whole));
         HIP_TRY(hipEventRecord(bnd, c->stream));
         ++c->last_launches;
     }
@@ -579,6 +581,10 @@ static int slab_rank_create_impl(int device, int nx, int NY, int rank, int nrank
     s->mfl.assign(NY, 0.0); s->mfr.assign(NY, 0.0);
     s->h_all.assign((size_t)nranks * 2 * s->maxown, 0.0);
     s->xchg = xchg; s->gather = gather; s->user = user;
+    // The grouped ncclSend/ncclRecv on a second stream, concurrent with the interior launch, has never run between two
+    // ranks (no multi-GPU box in this pipeline): until it has, the RCCL transport exchanges on the solver's stream unless
+    // the caller asks for the overlap (slab_overlap 1 / 2).  The host-staged transport is verified and keeps it.
+    s->overlap = xchg ? 1 : 0;
     const size_t blk = (size_t)SLAB_HALO * s->nx;
     if (xchg) {
         s->h_send_up.assign(blk, 0.0); s->h_send_dn.assign(blk, 0.0);

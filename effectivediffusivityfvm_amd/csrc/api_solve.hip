@@ -145,6 +145,46 @@ static int wgl_resident_blocks(const deff_ctx *c, int R, bool fma, bool guard, i
     return DEFF_OK;
 }
 
+// link-symmetric 12-wave tiles (kernels_wgtile.hpp, k_sweep_wgsym): T = 8, R in WGS_ROWS
+#define WGS_DISPATCH(R_, F_, CALL)                                                              \
+    do {                                                                                       \
+        if ((R_) == 3) { if (F_) { CALL(8, 3, true); } else { CALL(8, 3, false); } }            \
+        else if ((R_) == 4) { if (F_) { CALL(8, 4, true); } else { CALL(8, 4, false); } }       \
+        else { if (F_) { CALL(8, 5, true); } else { CALL(8, 5, false); } }                      \
+    } while (0)
+// (R = 6 -- 72-row tiles, images up to ~1230^2 -- needs 168 VGPRs + ~100 B of scratch inside the sweep loop: not instantiated)
+static const int WGS_ROWS[] = {3, 4, 5};
+static bool wgs_has_R(int R) { for (int r : WGS_ROWS) if (r == R) return true; return false; }
+
+template <int T, int R, bool F>
+static int wgs_occ(int *per_cu)
+{
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_sweep_wgsym<T, R, F>, WGS_WAVES * 64, 0));
+    return DEFF_OK;
+}
+
+static int wgs_resident_blocks(const deff_ctx *c, int R, bool fma, int *resident)
+{
+    static std::mutex mu;
+    static int cache[64][8][2];
+    const int d = c->device;
+    if (d >= 0 && d < 64 && R >= 0 && R < 8) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (cache[d][R][fma] > 0) { *resident = cache[d][R][fma]; return DEFF_OK; }
+    }
+    int per_cu = 0, cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+#define OCC_CALL(T_, R_, C_) TRY((wgs_occ<T_, R_, C_>(&per_cu)))
+    WGS_DISPATCH(R, fma, OCC_CALL);
+#undef OCC_CALL
+    *resident = per_cu * cus;
+    if (d >= 0 && d < 64 && R >= 0 && R < 8 && *resident > 0) {
+        std::lock_guard<std::mutex> lock(mu);
+        cache[d][R][fma] = *resident;
+    }
+    return DEFF_OK;
+}
+
 template <int T, int R, bool F, bool G>
 static int wgr_occ(int *per_cu)
 {
@@ -190,10 +230,10 @@ static hipError_t resident_chain_end(const deff_ctx *c)
     return hipEventRecord(g_res_ev[d], c->stream);
 }
 
-template <int T, int R, bool F, bool G, bool TALL = false, bool SYM = false>
-static hipError_t launch_wgres(deff_ctx *c, const SweepPlan &pl, double *xa, double *xb, int npass, unsigned base)
+template <class Kernel>
+static hipError_t launch_resident(deff_ctx *c, const SweepPlan &pl, Kernel kernel, int threads, double *xa, double *xb, int npass,
+                                  unsigned base)
 {
-    constexpr int THREADS = (TALL ? WGL_WAVES : WGT_WAVES) * 64;
     unsigned long long *stamps = c->tb_stamps;
     unsigned xbytes = (unsigned)(c->n * sizeof(double));
     int stall_tile = c->tb_debug_stall - 1;
@@ -205,25 +245,35 @@ static hipError_t launch_wgres(deff_ctx *c, const SweepPlan &pl, double *xa, dou
     const uint8_t *mask = c->masked ? c->active : nullptr;
     double omw = pl.omw;
     unsigned *flags = c->res_flags, *abort_flag = c->res_abort;
-    if (!c->tb_coop || c->coop_launch <= 0) {
-        std::lock_guard<std::mutex> lock(g_res_mu);
-        hipError_t e = resident_chain_begin(c);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_sweep_wgres<T, R, F, G, TALL, SYM>), dim3(pl.tblocks), dim3(THREADS), 0, c->stream, lut, code, xa,
-                           xb, nx, ny, img_stride, dom_lo, own_lo, own_h, cpi, ly, mask, ntx, gy, xmajor, allb, nrows, shift,
-                           omw, npass, flags, base, abort_flag, xbytes, stall_tile, stamps);
-        e = hipPeekAtLastError();
-        if (e != hipSuccess) return e;
-        return resident_chain_end(c);
-    }
-    void *args[] = {&lut, &code, &xa, &xb, &nx, &ny, &img_stride, &dom_lo, &own_lo, &own_h, &cpi, &ly, &mask, &ntx, &gy,
-                    &xmajor, &allb, &nrows, &shift, &omw, &npass, &flags, &base, &abort_flag, &xbytes, &stall_tile, &stamps};
-    return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&k_sweep_wgres<T, R, F, G, TALL, SYM>), dim3(pl.tblocks),
-                                      dim3(THREADS), args, 0, c->stream);
+    std::lock_guard<std::mutex> lock(g_res_mu);
+    hipError_t e = resident_chain_begin(c);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(pl.tblocks), dim3(threads), 0, c->stream, lut, code, xa,
+                       xb, nx, ny, img_stride, dom_lo, own_lo, own_h, cpi, ly, mask, ntx, gy, xmajor, allb, nrows, shift,
+                       omw, npass, flags, base, abort_flag, xbytes, stall_tile, stamps);
+    e = hipPeekAtLastError();
+    if (e != hipSuccess) return e;
+    return resident_chain_end(c);
+}
+
+template <int T, int R, bool F, bool G, bool TALL = false, bool SYM = false>
+static hipError_t launch_wgres(deff_ctx *c, const SweepPlan &pl, double *xa, double *xb, int npass, unsigned base)
+{
+    return launch_resident(c, pl, k_sweep_wgres<T, R, F, G, TALL, SYM>, (TALL ? WGL_WAVES : WGT_WAVES) * 64, xa, xb, npass, base);
+}
+
+template <int T, int R, bool F>
+static hipError_t launch_wgsym(deff_ctx *c, const SweepPlan &pl, double *xa, double *xb, int npass, unsigned base)
+{
+    return launch_resident(c, pl, k_sweep_wgsym<T, R, F>, WGS_WAVES * 64, xa, xb, npass, base);
 }
 
 // Did a resident launch give up?  Reads the flag (one 4-byte copy + a stream synchronisation) only when such a launch was
-// enqueued since the last look.  A raised flag means some tile stopped updating: the field is not a Jacobi iterate.
+// enqueued since the last look.  A raised flag means some tile stopped updating -- another process's kernels held part of
+// the chip, a CU mask -- and what the buffers hold is not a Jacobi iterate.  Nothing is lost: the field the interval started
+// from was copied aside in front of its first resident launch (enqueue_sweeps), so the interval is redone from that copy
+// with one launch per pass, and the context keeps launching that way (the condition that starved the tiles is not ours
+// to lift).  The caller sees the same bits it would have seen; deff_get_plan("tb_fallbacks") counts the occurrences.
 int resident_check(deff_ctx *c)
 {
     if (!c->res_pending) return DEFF_OK;
@@ -231,12 +281,25 @@ int resident_check(deff_ctx *c)
     HIP_TRY(hipMemcpyAsync(&h, c->res_abort, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->res_pending = false;
-    if (h) {
-        HIP_TRY(hipMemsetAsync(c->res_abort, 0, sizeof h, c->stream));
+    const int64_t redo = c->res_redo;
+    c->res_redo = 0;
+    if (!h) return DEFF_OK;
+    HIP_TRY(hipMemsetAsync(c->res_abort, 0, sizeof h, c->stream));
+    c->tb_resident = 0;
+    ++c->res_fallbacks;
+    c->tb_debug_stall = 0;
+    if (!c->res_backup) {
         c->have_field = false;
-        return fail(DEFF_EHIP, "resident passes aborted: a workgroup waited more than 2 s for a neighbouring tile "
-                               "(the field is invalid; set tuning tb_launch = 1 to launch every pass separately)");
+        return fail(DEFF_EHIP, "resident passes aborted and no restart copy exists (the field is invalid)");
     }
+    HIP_TRY(hipMemcpyAsync(c->x[c->res_backup_cur], c->res_backup, sizeof(double) * c->n, hipMemcpyDeviceToDevice, c->stream));
+    c->cur = c->res_backup_cur;
+    SweepPlan pl;
+    TRY(plan_sweeps(c, c->res_omega, &pl));
+    const int64_t launches = c->last_launches;
+    TRY(enqueue_sweeps(c, pl, redo));
+    c->last_launches = launches;                                   // (the redone launches are not the caller's)
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return DEFF_OK;
 }
 
@@ -364,6 +427,10 @@ static int check_links_symmetric(deff_ctx *c)
     if (c->links_sym != 0) return DEFF_OK;
     unsigned h = 1;
     TRY(resident_check(c));                                        // the abort word doubles as this kernel's flag: read it first
+    if (!c->res_abort) {
+        TRY(dev_alloc(&c->res_abort, 1));
+        HIP_TRY(hipMemsetAsync(c->res_abort, 0, sizeof(unsigned), c->stream));
+    }
     unsigned *flag = c->res_abort;
     HIP_TRY(hipMemsetAsync(flag, 0, sizeof(unsigned), c->stream));
     hipLaunchKernelGGL(k_links_symmetric, dim3(grid_for(c->n, 2048)), dim3(256), 0, c->stream, c->lut, c->code, c->nx, c->rows,
@@ -392,21 +459,23 @@ static void plan_strips(const deff_ctx *c, int T, SweepPlan *pl)
     pl->ntx = use_b ? ntx_b : ntx_a;
 }
 
-// flags (one 256-byte block per tile) and the abort word of the resident launches
+// flags (one 256-byte block per tile) and the abort word of the resident launches.  A flag holds the number of passes its
+// tile has completed since the array was last cleared (c->res_epoch, compared through a signed difference in the kernel):
+// a new array starts a new count, and so does an old one before the count could wrap (launch_resident_passes).
 static int ensure_resident_buffers(deff_ctx *c, long tiles)
 {
     if (c->res_flags_n < (size_t)tiles) {
+        TRY(resident_check(c));                                     // nothing resident may still be using the old array
         if (c->res_flags) { HIP_TRY(hipFree(c->res_flags)); c->res_flags = nullptr; }
         TRY(dev_alloc(&c->res_flags, (size_t)tiles * WGR_FLAG_STRIDE));
         HIP_TRY(hipMemsetAsync(c->res_flags, 0, sizeof(unsigned) * tiles * WGR_FLAG_STRIDE, c->stream));
         c->res_flags_n = (size_t)tiles;
+        c->res_epoch = 0;
     }
     if (!c->res_abort) {
         TRY(dev_alloc(&c->res_abort, 1));
         HIP_TRY(hipMemsetAsync(c->res_abort, 0, sizeof(unsigned), c->stream));
     }
-    if (c->coop_launch < 0)
-        HIP_TRY(hipDeviceGetAttribute(&c->coop_launch, hipDeviceAttributeCooperativeLaunch, c->device));
     return DEFF_OK;
 }
 
@@ -423,7 +492,7 @@ static bool resident_allowed(const deff_ctx *c, const SweepPlan *pl)
 static int choose_tall_R(const deff_ctx *c, const SweepPlan *pl, int T, int own_h, int *tall_R)
 {
     *tall_R = 0;
-    if (T != 8 || !resident_allowed(c, pl) || c->tb_NW == WGT_WAVES) return DEFF_OK;
+    if (T != 8 || !resident_allowed(c, pl) || c->tb_NW == WGT_WAVES || c->tb_NW == WGS_WAVES) return DEFF_OK;
     if (c->tb_NW != WGL_WAVES && (c->tb_R != 0 || c->tb_LY != 0)) return DEFF_OK;
     for (int R : WGL_ROWS) {
         if (c->tb_NW == WGL_WAVES && wgl_has_R(c->tb_R) && R != c->tb_R) continue;
@@ -507,6 +576,55 @@ static int plan_tall(deff_ctx *c, SweepPlan *pl, int T, int own_h, int R)
     return DEFF_OK;
 }
 
+// Link-symmetric 12-wave tiles (k_sweep_wgsym): matrix rows in registers at 3 waves per SIMD.  A tile of 12 x R rows has the
+// shape of an 8-wave tile of 1.5 R rows and sweeps it faster (three waves of a SIMD issue FP64 every ~5 clocks, two every ~6),
+// so wherever the system is verified link-symmetric and unguarded this form replaces the 8-wave tiles: the fewest rows per
+// wave whose tiles all fit the chip.  *R = 0: not applicable (not symmetric, guarded, too many tiles, caller insists on
+// another form).  T = 8, resident launches only.
+static int choose_sym_R(deff_ctx *c, const SweepPlan *pl, int T, int own_h, int *sym_R)
+{
+    *sym_R = 0;
+    if (T != 8 || !resident_allowed(c, pl) || c->lut_guard || c->tb_sym == 2) return DEFF_OK;
+    if (c->tb_NW != 0 && c->tb_NW != WGS_WAVES) return DEFF_OK;
+    if (c->tb_NW != WGS_WAVES && (c->tb_R != 0 || c->tb_LY != 0)) return DEFF_OK;
+    int found = 0;
+    for (int R : WGS_ROWS) {
+        if (c->tb_NW == WGS_WAVES && wgs_has_R(c->tb_R) && R != c->tb_R) continue;
+        const int lymax = wgs_rows_owned(T, R);
+        const int cpi = (own_h + lymax - 1) / lymax;
+        const int LY = (own_h + cpi - 1) / cpi;
+        if (LY < T && cpi > 1) continue;                            // a tile's halo must end inside its immediate neighbours
+        const long tiles = (long)pl->ntx * cpi * c->nimg;
+        int res = 0;
+        TRY(wgs_resident_blocks(c, R, pl->fma, &res));
+        if (((tiles + 7) / 8) * 8 <= res) { found = R; break; }
+    }
+    if (!found) return DEFF_OK;
+    TRY(check_links_symmetric(c));                                  // once per (codes, dictionary): one pass over the codes
+    if (c->links_sym == 1) *sym_R = found;
+    return DEFF_OK;
+}
+
+static int plan_sym(deff_ctx *c, SweepPlan *pl, int T, int own_h, int R)
+{
+    pl->impl = 2;
+    pl->NW = WGS_WAVES;
+    pl->R = R;
+    pl->guard = false;
+    const int lymax = wgs_rows_owned(T, R);
+    const int cpi = (own_h + lymax - 1) / lymax;
+    pl->LY = (own_h + cpi - 1) / cpi;
+    pl->tcpi = (own_h + pl->LY - 1) / pl->LY;
+    pl->tgy = pl->tcpi * c->nimg;
+    const long tiles = (long)pl->ntx * pl->tgy;
+    pl->tgx = (int)tiles;
+    pl->tblocks = (int)(((tiles + 7) / 8) * 8);
+    pl->resident = true;
+    pl->sym = true;
+    TRY(ensure_resident_buffers(c, tiles));
+    return DEFF_OK;
+}
+
 // Streaming form: rows per chunk.  Workgroups are persistent, so a pass takes `rounds` tiles per wave slot (one round = as
 // many wave tiles as are resident at once), and a tile costs its LY rows + T steps that drain the pipeline + T rows of halo
 // above it unless it starts at the top wall of its image + a fixed start-up (first loads, measured ~8 row steps).  Pick the
@@ -574,15 +692,24 @@ static int plan_blocked_pass(deff_ctx *c, SweepPlan *pl)
     pl->own_lo = own_lo;
     pl->own_h = own_h;
     plan_strips(c, T, pl);
-    int tall_R = 0;
+    int tall_R = 0, sym_R = 0;
     TRY(choose_tall_R(c, pl, T, own_h, &tall_R));
     int want_impl = c->tb_impl ? c->tb_impl : default_tb_impl(c);
     // a context just above the 4 Mi cells where the streaming form takes over still runs faster on tall tiles when they fit
     if (!c->tb_impl && want_impl == 1 && tall_R) want_impl = 2;
     // workgroup tiles exist for T = 4 and 8; slabs' T = 1 remainder passes and the other T stay on the streaming kernel
     if (want_impl == 2 && (T == 4 || T == 8) && !pl->T_override) {
-        TRY(plan_tiles8(c, pl, T, own_h));
-        if (tall_R && (!pl->resident || c->tb_NW == WGL_WAVES)) TRY(plan_tall(c, pl, T, own_h, tall_R));
+        // images that are ONE tall tile each (a stack of 128^2 images) recompute nothing and wait for nobody: nothing beats that
+        const bool tall_whole = tall_R && pl->ntx == 1 && wgl_row_tiles(own_h, tall_R, T) == 1;
+        if (!tall_whole) TRY(choose_sym_R(c, pl, T, own_h, &sym_R));
+        if (tall_whole && c->tb_NW != WGT_WAVES) {
+            TRY(plan_tall(c, pl, T, own_h, tall_R));
+        } else if (sym_R) {
+            TRY(plan_sym(c, pl, T, own_h, sym_R));
+        } else {
+            TRY(plan_tiles8(c, pl, T, own_h));
+            if (tall_R && (!pl->resident || c->tb_NW == WGL_WAVES)) TRY(plan_tall(c, pl, T, own_h, tall_R));
+        }
     } else {
         TRY(plan_streaming(c, pl, T, own_lo, own_h));
     }
@@ -599,6 +726,7 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl)
         TRY(try_dict(c));
     TRY(resolve_kernel(c, &pl->kernel));
     pl->fma = c->fma != 0;
+    pl->omega = omega;
     pl->omw = 1.0 - omega;                              // cuh:89 evaluates (1.0 - w) in double
     if (pl->kernel == DEFF_KERNEL_MATFREE || pl->kernel == DEFF_KERNEL_MATFREE_TB) {
         TRY(upload_lut(c, omega));
@@ -683,20 +811,22 @@ void enqueue_sweep(deff_ctx *c, const SweepPlan &pl)
 }
 
 // One temporally blocked pass: T sweeps, x[cur] -> x[cur^1].
-void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl)
+int enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl)
 {
-    launch_tb_pass(c, pl);
+    TRY(launch_tb_pass(c, pl));
     c->cur ^= 1;
+    return DEFF_OK;
 }
 
 // The launch of a pass (or of one band of it: pl.own_lo / pl.own_h) without the buffer flip.
-void launch_tb_pass(deff_ctx *c, const SweepPlan &pl)
+int launch_tb_pass(deff_ctx *c, const SweepPlan &pl)
 {
     const double *xin = c->x[c->cur];
     double *xout = c->x[c->cur ^ 1];
     const int flip = c->serpentine ? c->cur : 0;
     const uint8_t *mask = c->masked ? c->active : nullptr;
-    if (pl.impl == 2 && pl.NW == WGL_WAVES) return;    // tall tiles only launch resident (enqueue_sweeps); reached only after a failed launch
+    if (pl.impl == 2 && pl.NW != WGT_WAVES)
+        return fail(DEFF_ESTATE, "tiles of %d waves only exist as resident launches (plan again with tb_launch = 1)", pl.NW);
     if (pl.impl == 2) {
 #define LAUNCH_WGT(T_, R_, C_, G_)                                                                             \
     hipLaunchKernelGGL((k_sweep_wgtile<T_, R_, C_, G_>), dim3(pl.tblocks), dim3(WGT_WAVES * 64), 0, c->stream, c->lut, \
@@ -705,7 +835,8 @@ void launch_tb_pass(deff_ctx *c, const SweepPlan &pl)
                        c->lut_nrows, pl.shift, pl.omw, c->tb_stamps)
         WGT_DISPATCH(pl.T, pl.R, pl.fma, pl.guard, LAUNCH_WGT);
 #undef LAUNCH_WGT
-        return;
+        HIP_TRY(hipPeekAtLastError());
+        return DEFF_OK;
     }
 #define LAUNCH_TB(T_, C_, G_)                                                                                  \
     hipLaunchKernelGGL((k_sweep_matfree_tb<T_, C_, G_>), dim3(pl.tblocks), dim3(256), 0, c->stream, c->lut,    \
@@ -715,43 +846,80 @@ void launch_tb_pass(deff_ctx *c, const SweepPlan &pl)
                        c->lut_nrows, pl.shift, pl.omw, c->tb_stamps)
     TB_DISPATCH(pl.T, pl.fma, pl.guard, LAUNCH_TB);
 #undef LAUNCH_TB
+    HIP_TRY(hipPeekAtLastError());
+    return DEFF_OK;
 }
 
-// n sweeps: as many T-sweep passes as fit, the rest one at a time.
-void enqueue_sweeps(deff_ctx *c, const SweepPlan &pl, int64_t n)
+// All whole passes of n sweeps as resident launches of up to 4 096 passes (tens of milliseconds each); *n is reduced by
+// the sweeps enqueued.  In front of the first resident launch since the abort flag was last looked at, the field is copied
+// aside: the restart point if a launch gives up (resident_check).
+static int launch_resident_passes(deff_ctx *c, const SweepPlan &pl, int64_t *n)
 {
-    if (pl.kernel == DEFF_KERNEL_MATFREE_TB && pl.impl == 2 && pl.resident && n >= (pl.NW == WGL_WAVES ? 1 : 2) * pl.T) {
-        // all whole passes in launches of up to 4 096 passes (tens of milliseconds each)
-        int64_t np = n / pl.T;
-        while (np > 0) {
-            const int chunk = (int)(np < 4096 ? np : 4096);
-            hipError_t e = hipSuccess;
-            if (pl.NW == WGL_WAVES) {
-                // (the symmetric short-cut exists in the unguarded kernels only: the guarded one branches on every link anyway)
+    int64_t np = *n / pl.T;
+    if (np > 0 && !c->res_pending) {
+        TRY(dev_alloc(&c->res_backup, c->n));
+        HIP_TRY(hipMemcpyAsync(c->res_backup, c->x[c->cur], sizeof(double) * c->n, hipMemcpyDeviceToDevice, c->stream));
+        c->res_backup_cur = c->cur;
+        c->res_redo = 0;
+        c->res_omega = pl.omega;
+    }
+    while (np > 0) {
+        const int chunk = (int)(np < 4096 ? np : 4096);
+        if (c->res_epoch > (1u << 30)) {
+            // the flags count passes since they were last cleared and are compared through a signed difference: start a
+            // new count long before it could wrap (stream-ordered: every earlier launch has finished with them)
+            HIP_TRY(hipMemsetAsync(c->res_flags, 0, sizeof(unsigned) * c->res_flags_n * WGR_FLAG_STRIDE, c->stream));
+            c->res_epoch = 0;
+        }
+        hipError_t e = hipSuccess;
+        if (pl.NW == WGS_WAVES) {
+#define LAUNCH_WGS(T_, R_, C_) e = launch_wgsym<T_, R_, C_>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch)
+            WGS_DISPATCH(pl.R, pl.fma, LAUNCH_WGS);
+#undef LAUNCH_WGS
+        } else if (pl.NW == WGL_WAVES) {
+            // (the symmetric short-cut exists in the unguarded kernels only: the guarded one branches on every link anyway)
 #define LAUNCH_WGL(T_, R_, C_, G_) e = launch_wgres<T_, R_, C_, G_, true, false>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch)
 #define LAUNCH_WGLS(T_, R_, C_, G_) e = launch_wgres<T_, R_, C_, false, true, true>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch)
-                if (pl.sym && !pl.guard) { WGL_DISPATCH(pl.R, pl.fma, false, LAUNCH_WGLS); }
-                else { WGL_DISPATCH(pl.R, pl.fma, pl.guard, LAUNCH_WGL); }
+            if (pl.sym && !pl.guard) { WGL_DISPATCH(pl.R, pl.fma, false, LAUNCH_WGLS); }
+            else { WGL_DISPATCH(pl.R, pl.fma, pl.guard, LAUNCH_WGL); }
 #undef LAUNCH_WGL
 #undef LAUNCH_WGLS
-            } else {
+        } else {
 #define LAUNCH_WGR(T_, R_, C_, G_) e = launch_wgres<T_, R_, C_, G_>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch)
-                WGT_DISPATCH(pl.T, pl.R, pl.fma, pl.guard, LAUNCH_WGR);
+            WGT_DISPATCH(pl.T, pl.R, pl.fma, pl.guard, LAUNCH_WGR);
 #undef LAUNCH_WGR
-            }
-            if (e != hipSuccess) break;                            // left in hipGetLastError() for the caller
-            c->res_epoch += (unsigned)chunk;
-            c->res_pending = true;
-            c->cur ^= (chunk & 1);
-            np -= chunk;
-            n -= (int64_t)chunk * pl.T;
-            ++c->last_launches;
         }
+        if (e != hipSuccess) return fail(DEFF_EHIP, "resident launch failed: %s", hipGetErrorString(e));
+        c->res_epoch += (unsigned)chunk;
+        c->res_pending = true;
+        c->cur ^= (chunk & 1);
+        np -= chunk;
+        *n -= (int64_t)chunk * pl.T;
+        c->res_redo += (int64_t)chunk * pl.T;
+        ++c->last_launches;
     }
-    if (pl.kernel == DEFF_KERNEL_MATFREE_TB) {
-        while (n >= pl.T) { enqueue_tb_pass(c, pl); n -= pl.T; ++c->last_launches; }
+    return DEFF_OK;
+}
+
+// n sweeps: as many T-sweep passes as fit, the rest one at a time.  Stops at the first launch that fails.
+int enqueue_sweeps(deff_ctx *c, const SweepPlan &pl, int64_t n)
+{
+    if (pl.kernel == DEFF_KERNEL_MATFREE_TB && pl.impl == 2 && pl.resident && !c->tb_resident) {
+        // the context fell back to one launch per pass (resident_check) after this plan was made
+        SweepPlan again;
+        TRY(plan_sweeps(c, pl.omega, &again));
+        if (again.resident) return fail(DEFF_ESTATE, "internal: plan still resident after the fallback");
+        return enqueue_sweeps(c, again, n);
     }
-    for (; n > 0; --n) { enqueue_sweep(c, pl); ++c->last_launches; }
+    // (while resident launches are in flight unchecked, whatever follows them is part of what a fallback must redo)
+    if (pl.kernel == DEFF_KERNEL_MATFREE_TB && pl.impl == 2 && pl.resident && n >= (pl.NW != WGT_WAVES ? 1 : 2) * pl.T)
+        TRY(launch_resident_passes(c, pl, &n));
+    if (pl.kernel == DEFF_KERNEL_MATFREE_TB && !(pl.impl == 2 && pl.NW != WGT_WAVES)) {
+        while (n >= pl.T) { TRY(enqueue_tb_pass(c, pl)); n -= pl.T; ++c->last_launches; if (c->res_pending) c->res_redo += pl.T; }
+    }
+    for (; n > 0; --n) { enqueue_sweep(c, pl); ++c->last_launches; if (c->res_pending) ++c->res_redo; }
+    HIP_TRY(hipPeekAtLastError());
+    return DEFF_OK;
 }
 
 extern "C" int deff_sweeps(deff_ctx *c, int64_t nsweeps, double omega, float *ms)
@@ -764,8 +932,7 @@ try {
     TRY(consolidate(c));
     c->last_launches = 0;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    enqueue_sweeps(c, pl, nsweeps);
-    HIP_TRY(hipGetLastError());
+    TRY(enqueue_sweeps(c, pl, nsweeps));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
     if (ms) HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
@@ -874,8 +1041,7 @@ try {
         const int64_t next_check = ((iter + check_every - 1) / check_every) * check_every;
         const bool do_check = next_check < max_iter;
         const int64_t batch = do_check ? next_check - iter + 1 : max_iter - iter;
-        enqueue_sweeps(c, pl, batch);
-        HIP_TRY(hipGetLastError());
+        TRY(enqueue_sweeps(c, pl, batch));
         iter += batch;
         for (int k = 0; k < B; ++k)
             if (c->active_h[k]) { iters[k] = iter; c->buf_of[k] = (uint8_t)c->cur; }
@@ -910,6 +1076,7 @@ try {
             }
         }
     }
+    TRY(resident_check(c));                                          // a solve that ends between two checks (MAX_ITER)
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
     float ms = 0;
@@ -938,6 +1105,7 @@ DEFF_API_CATCH
 // put image `slot`'s pixels / codes / wall data / linear guess in place (2-phase native system)
 static int stream_load_slot(deff_ctx *c, int slot, const uint8_t *pix_host)
 {
+    TRY(resident_check(c));                            // the restart copy of a resident interval predates this slot's new image
     const size_t npix = (size_t)c->W * c->H;
     uint8_t *dpix = c->pix + (size_t)slot * npix;
     uint16_t *dcode = c->code + (size_t)slot * c->n_img;
@@ -957,6 +1125,7 @@ static int stream_load_slot(deff_ctx *c, int slot, const uint8_t *pix_host)
 
 static int stream_push_mask(deff_ctx *c, int n_active)
 {
+    TRY(resident_check(c));                            // ... and the mask the interval ran under
     bool all = true;
     for (int k = 0; k < c->nimg; ++k) all = all && c->active_h[k];
     c->masked = !all && n_active > 0;
@@ -1031,8 +1200,7 @@ try {
     };
     auto advance = [&](SweepPlan &pl, int64_t nsw) -> int {
         if (nsw <= 0) return DEFF_OK;
-        enqueue_sweeps(c, pl, nsw);
-        HIP_TRY(hipGetLastError());
+        TRY(enqueue_sweeps(c, pl, nsw));
         for (int k = 0; k < B; ++k)
             if (S[k].live) { S[k].iters += nsw; c->buf_of[k] = (uint8_t)c->cur; }
         return DEFF_OK;
@@ -1104,6 +1272,9 @@ try {
         if (pl.impl == 2 && pl.NW == WGL_WAVES && c->tb_sym != 2 && c->links_sym == 0) {
             TRY(check_links_symmetric(c));
             pl.sym = c->links_sym == 1;
+        } else if (pl.impl == 2 && pl.NW == WGS_WAVES && c->links_sym == 0) {
+            TRY(check_links_symmetric(c));
+            if (c->links_sym != 1) { pl = SweepPlan(); TRY(plan_sweeps(c, omega, &pl)); }   // (never for the native assembly)
         }
     }
     c->masked = false;
@@ -1138,8 +1309,10 @@ try {
     if (!out) return DEFF_OK;
     HIP_TRY(hipMalloc((void **)&c->tb_stamps, sizeof(unsigned long long) * 2 * n));
     HIP_TRY(hipMemsetAsync(c->tb_stamps, 0, sizeof(unsigned long long) * 2 * n, c->stream));
-    if (pl.impl == 2 && pl.resident && pl.T == 8) enqueue_sweeps(c, pl, 3 * pl.T);   // k_sweep_wgres: 12 stamps per tile, 3 passes
-    else enqueue_tb_pass(c, pl);
+    int rc = DEFF_OK;
+    if (pl.impl == 2 && pl.resident && pl.T == 8) rc = enqueue_sweeps(c, pl, 3 * pl.T);   // k_sweep_wgres: 12 stamps per tile, 3 passes
+    else rc = enqueue_tb_pass(c, pl);
+    if (rc != DEFF_OK) { (void)hipFree(c->tb_stamps); c->tb_stamps = nullptr; return rc; }
     hipError_t e = hipMemcpyAsync(out, c->tb_stamps, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(c->tb_stamps);

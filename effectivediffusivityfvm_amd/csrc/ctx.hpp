@@ -149,13 +149,13 @@ struct deff_ctx {
     int tb_impl = 0, tb_R = 0, tb_NW = 0;
     // resident passes (kernels_wgtile.hpp, k_sweep_wgres): when every tile of the context is on the chip at once, all the
     // passes between two checks are ONE launch whose tiles keep their matrix rows and owned cells in registers and wait
-    // for their neighbours only.  Tuning key "tb_launch": 0 = resident passes whenever the tiles are co-resident, through
-    // a plain launch (default: the grid fits the chip by the occupancy query, resident launches of one process are chained
-    // per device, api_solve.hip, so that two of them never share the chip, and every wait is bounded); 1 = never (one
-    // launch per pass); 2 = resident through hipLaunchCooperativeKernel, which makes the runtime vouch for co-residency --
-    // not the default because ROCm 7.2's teardown segfaults at process exit once several host threads have launched
-    // cooperatively (deff2d --devices 0,0,0).
-    int tb_resident = 1, tb_coop = 0;
+    // for their neighbours only.  Tuning key "tb_launch": 0 = resident passes whenever the tiles are co-resident (default:
+    // the grid fits the chip by the occupancy query, resident launches of one process are chained per device,
+    // api_solve.hip, so that two of them never share the chip, and every wait is bounded); 1 = never (one launch per pass).
+    // What the process cannot rule out -- another PROCESS on the same GPU, a CU mask -- ends in a bounded wait running
+    // out; the solve then restores the field it had when the interval's first resident launch was enqueued, redoes the
+    // interval with one launch per pass and stays in that mode (res_fallbacks counts these; deff_get_plan "tb_fallbacks").
+    int tb_resident = 1;
     // is the matrix-free system link-symmetric (k_links_symmetric)?  0 = not looked at since the codes / dictionary last
     // changed, 1 = yes (tall tiles then do 7 lookups per row instead of 10), 2 = no
     int links_sym = 0;
@@ -167,7 +167,13 @@ struct deff_ctx {
     unsigned res_epoch = 0;
     unsigned *res_abort = nullptr;               // raised by a workgroup whose wait for a neighbour ran out
     bool res_pending = false;                    // a resident launch was enqueued since the flag was last read
-    int coop_launch = -1;                        // hipDeviceAttributeCooperativeLaunch, cached
+    // restart point of the resident launches in flight: a copy of x[res_backup_cur] taken in front of the first resident
+    // launch after a synchronised look at the abort flag, and the sweeps enqueued since (with their omega)
+    double *res_backup = nullptr;
+    int res_backup_cur = 0;
+    int64_t res_redo = 0;
+    double res_omega = 0;
+    int res_fallbacks = 0;                       // aborted resident intervals redone with one launch per pass
     int fma = 0;                                 // contracted arithmetic (kernels_sweep.hpp), opt-in
     int tb_xmajor = 1;                           // wave-tile numbering of the temporally blocked kernel
     int64_t last_launches = 0;                   // sweep-kernel launches of the last deff_sweeps()/deff_solve()
@@ -273,6 +279,7 @@ struct SweepPlan {
     int shift = 0;                                        // column shift of the strips (0: no halo outside the walls)
     int T_override = 0;                                   // slab mode plans a T = 1 pass for remainders
     bool guard = false;
+    double omega = 0;                                     // as given to plan_sweeps (omw = 1 - omega)
     int impl = 1, R = 0, NW = 8;                          // 1 = streaming kernel, 2 = workgroup tiles of NW waves x R rows
     bool resident = false;                                // impl 2 only: all passes of a batch in one launch (k_sweep_wgres)
     bool sym = false;                                     // tall tiles: the system is link-symmetric (7 lookups per row)
@@ -295,8 +302,10 @@ int clamp_tb_T(int T);
 int default_tb_impl(const deff_ctx *c);
 int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl);
 void enqueue_sweep(deff_ctx *c, const SweepPlan &pl);
-void enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl);
-void launch_tb_pass(deff_ctx *c, const SweepPlan &pl);   // the same launch without flipping x[cur]
-void enqueue_sweeps(deff_ctx *c, const SweepPlan &pl, int64_t n);
-int resident_check(deff_ctx *c);                         // did a resident launch give up waiting?  (synchronises if one is pending)
+int enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl);
+int launch_tb_pass(deff_ctx *c, const SweepPlan &pl);    // the same launch without flipping x[cur]
+int enqueue_sweeps(deff_ctx *c, const SweepPlan &pl, int64_t n);   // stops at the first launch that fails
+// did a resident launch give up waiting?  (synchronises if one is pending; on an abort the interval is redone with one
+// launch per pass and the context stays in that mode)
+int resident_check(deff_ctx *c);
 int flux_rows(deff_ctx *c, bool need_rows = true);

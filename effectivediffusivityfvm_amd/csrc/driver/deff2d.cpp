@@ -9,7 +9,7 @@
 // --field-bin dumps the FP64 concentration field.
 //
 //   deff2d [input.txt] [--device N | --devices 0,1,..] [--json results.json] [--field-bin prefix] [--batch-size B]
-//          [--progress file] [--arith reference|contracted]
+//          [--progress file] [--arith reference|contracted] [--precond-maxiter N]
 // --arith contracted: products fused into adds the way a compiler contracts the reference's expressions
 // (kernels_sweep.hpp); default is the reference's written operation order.
 //
@@ -106,6 +106,9 @@ static std::vector<unsigned int> grid_of(const Image &im, const Options &o, int 
 }
 
 static int g_contracted = 0;       // --arith contracted: deff_set_tuning(ctx, "fma", 1) on every context
+// MAX_ITER of the 3-phase continuation stages: the reference's literal 1e6 (cuh:1503).  --precond-maxiter N replaces it so
+// that a capped run of a large image fits a CPU oracle run (tests/golden/make_img00042_golden.py); not an input.txt key.
+static int64_t g_precond_maxiter = 1000000;
 
 struct Session {                   // one solver context, re-created only when the mesh / batch size changes
     deff_ctx *ctx = nullptr;
@@ -269,7 +272,7 @@ static bool solve_3phase(Target &&T, const Image &im, const Options &o, Row *row
         if (o.verbose == 1) std::printf("Pre-Cond Stage %d: DCG = %1.3e\n", stage_no, g);
         if (!T.assemble3(o, g, grid.data())) return false;
         deff_result r;
-        if (!T.solve_with(o, o.ConvergeCriteria * 10, 1000000, false, nullptr, &r)) return false;
+        if (!T.solve_with(o, o.ConvergeCriteria * 10, g_precond_maxiter, false, nullptr, &r)) return false;
         if (o.verbose == 1) std::printf("Iterations taken = %ld\n", (long)r.iters);
         row->stages.push_back((long)r.iters);
     }
@@ -339,7 +342,7 @@ static bool solve_3phase_group(Session &S, const std::vector<Image> &ims, const 
     for (double g = 10; g < DCG; g *= 10, ++stage_no) {              // JacobiGPUPreCond stages, cuh:2184-2326
         if (o.verbose == 1) std::printf("Pre-Cond Stage %d: DCG = %1.3e\n", stage_no, g);
         CK(deff_assemble_3phase(S.ctx, DCS, DCF, g, grid.data(), o.CLeft, o.CRight));
-        CK(deff_solve_batch(S.ctx, 2.0 / 3.0, o.ConvergeCriteria * 10, 1000000, 10000, res.data(), nullptr, nullptr));
+        CK(deff_solve_batch(S.ctx, 2.0 / 3.0, o.ConvergeCriteria * 10, g_precond_maxiter, 10000, res.data(), nullptr, nullptr));
         for (int k = 0; k < B; ++k) rows[k].stages.push_back((long)res[k].iters);
     }
     CK(deff_assemble_3phase(S.ctx, DCS, DCF, DCG, grid.data(), o.CLeft, o.CRight));
@@ -638,8 +641,12 @@ int main(int argc, char **argv)
             else if (v == "reference" || v == "plain") g_contracted = 0;
             else { std::fprintf(stderr, "deff2d: --arith takes 'reference' or 'contracted'\n"); return 2; }
         }
+        else if (s == "--precond-maxiter" && a + 1 < argc) {
+            g_precond_maxiter = (int64_t)std::strtod(argv[++a], nullptr);
+            if (g_precond_maxiter < 1) { std::fprintf(stderr, "deff2d: --precond-maxiter must be >= 1\n"); return 2; }
+        }
         else if (s == "-h" || s == "--help") {
-            std::printf("usage: deff2d [input.txt] [--device N] [--json results.json] [--field-bin prefix] [--batch-size B] [--devices 0,1,...] [--progress file] [--arith reference|contracted]\n");
+            std::printf("usage: deff2d [input.txt] [--device N] [--json results.json] [--field-bin prefix] [--batch-size B] [--devices 0,1,...] [--progress file] [--arith reference|contracted] [--precond-maxiter N]\n");
             return 0;
         } else if (!s.empty() && s[0] != '-') input = s;
         else { std::fprintf(stderr, "deff2d: unknown argument %s\n", s.c_str()); return 2; }

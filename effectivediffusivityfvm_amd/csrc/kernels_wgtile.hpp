@@ -510,6 +510,155 @@ __device__ __forceinline__ void wgl_sweeps(double2 (&xr)[R], const unsigned *cod
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Link-symmetric tiles (resident form only): the 8-wave form's idea -- the matrix rows of a wave's cells stay in registers,
+// a sweep is pure arithmetic -- at 14 instead of 20 VGPRs per tile row, which is what lets THREE waves per SIMD (12 per
+// workgroup, 168 VGPRs) hold a tile.  A link belongs to a face: the W link of a lane's second cell IS the E link of its
+// first, and the N links of a row ARE the S links of the row above it, which the same wave holds (row 0 of a wave keeps
+// its own N links: 4 VGPRs per wave).  Same values, so the same bits -- provided the system at hand really is
+// link-symmetric, which k_links_symmetric verifies on the device per assembly (api_solve.hip, plan key tb_sym), exactly as
+// for the tall tiles' 7-lookup rows.  What it buys: an FP64 instruction issues every ~5.0 clocks from three waves of a SIMD
+// against ~6.1 from two (tools/ubench), and a tile of 12 x R rows has the shape of an 8-wave tile of 1.5 R rows:
+// one 1024^2 image is 9 x 24 tiles of 12 x 5 rows (44 owned) instead of 9 x 26 of 8 x 7 (40 owned).
+constexpr int WGS_WAVES = 12;
+constexpr int wgs_rows_owned(int T, int R) { return WGS_WAVES * R - 2 * T; }
+
+template <int R>
+struct WgsCoef {
+    double2 c0[R];      // w/A0 of the lane's two cells
+    double aW0[R];      // W link of the first cell (the second cell's W link is aE[].x)
+    double2 aE[R];      // E links
+    double2 aS[R];      // S links (row r + 1 takes them as its N links)
+    double2 aN0;        // N links of the wave's first row
+};
+
+template <int R, bool WALL>
+__device__ __forceinline__ void wgs_lookup(const double *lut, const unsigned (&cc)[R], WgsCoef<R> &k, double2 (&bb)[WALL ? R : 1])
+{
+    constexpr int PS = LUT_PLANE_STRIDE * 8;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const char *b0 = reinterpret_cast<const char *>(lut) + (cc[r] & 0xFFFFu);
+        const char *b1 = reinterpret_cast<const char *>(lut) + (cc[r] >> 16);
+        k.c0[r] = make_double2(*reinterpret_cast<const double *>(b0), *reinterpret_cast<const double *>(b1));
+        k.aW0[r] = *reinterpret_cast<const double *>(b0 + PS);
+        k.aE[r] = make_double2(*reinterpret_cast<const double *>(b0 + 2 * PS), *reinterpret_cast<const double *>(b1 + 2 * PS));
+        k.aS[r] = make_double2(*reinterpret_cast<const double *>(b0 + 3 * PS), *reinterpret_cast<const double *>(b1 + 3 * PS));
+        if (r == 0) k.aN0 = make_double2(*reinterpret_cast<const double *>(b0 + 4 * PS), *reinterpret_cast<const double *>(b1 + 4 * PS));
+        if constexpr (WALL) bb[r] = make_double2(*reinterpret_cast<const double *>(b0 + 5 * PS), *reinterpret_cast<const double *>(b1 + 5 * PS));
+    }
+}
+
+// NROWS tile rows together, stage-wise (see wgt_rows); per cell tb_apply()'s operations in tb_apply()'s order.
+template <int NROWS, bool FMA>
+__device__ __forceinline__ void wgs_rows(const double2 (&c0)[NROWS], const double (&aW0)[NROWS], const double2 (&aE)[NROWS],
+                                         const double2 (&aS)[NROWS], const double2 (&aN)[NROWS], const double2 (&b)[NROWS],
+                                         const double2 (&n_)[NROWS], const double2 (&c_)[NROWS], const double2 (&s_)[NROWS],
+                                         double omw, double2 (&out)[NROWS])
+{
+    double s0[NROWS], s1[NROWS], m0[NROWS], m1[NROWS];
+#pragma unroll
+    for (int q = 0; q < NROWS; ++q) { s0[q] = aW0[q] * from_lane_below(c_[q].y); s1[q] = aE[q].x * c_[q].x; }
+#pragma unroll
+    for (int q = 0; q < NROWS; ++q) { s0[q] = mul_add<FMA>(aE[q].x, c_[q].y, s0[q]); s1[q] = mul_add<FMA>(aE[q].y, from_lane_above(c_[q].x), s1[q]); }
+#pragma unroll
+    for (int q = 0; q < NROWS; ++q) { s0[q] = mul_add<FMA>(aS[q].x, s_[q].x, s0[q]); s1[q] = mul_add<FMA>(aS[q].y, s_[q].y, s1[q]); }
+#pragma unroll
+    for (int q = 0; q < NROWS; ++q) { s0[q] = mul_add<FMA>(aN[q].x, n_[q].x, s0[q]); s1[q] = mul_add<FMA>(aN[q].y, n_[q].y, s1[q]); }
+#pragma unroll
+    for (int q = 0; q < NROWS; ++q) { s0[q] = b[q].x - s0[q]; s1[q] = b[q].y - s1[q]; }
+    if constexpr (!FMA) {
+#pragma unroll
+        for (int q = 0; q < NROWS; ++q) { m0[q] = omw * c_[q].x; m1[q] = omw * c_[q].y; }
+    }
+#pragma unroll
+    for (int q = 0; q < NROWS; ++q) { s0[q] = c0[q].x * s0[q]; s1[q] = c0[q].y * s1[q]; }
+#pragma unroll
+    for (int q = 0; q < NROWS; ++q) {
+        if constexpr (FMA) out[q] = make_double2(__builtin_fma(omw, c_[q].x, s0[q]), __builtin_fma(omw, c_[q].y, s1[q]));
+        else out[q] = make_double2(m0[q] + s0[q], m1[q] + s1[q]);
+    }
+}
+
+// The T sweeps of a wave's R rows, in place: wgt_sweeps' schedule (publish the edge rows, interior rows, barrier, edge rows)
+// on the symmetric coefficient set; every wave of the workgroup must call this.
+// (Measured and dropped: handing every row to the rim store as soon as its value of the pass's LAST sweep exists, so that the
+// stores travel while the rest of that sweep is computed.  The flag of a pass waits for the acknowledgement of the LAST store,
+// and the rows finished last -- each wave's two edge rows, behind the sweep's barrier -- all hold rim cells: "rim stored +
+// flag raised" fell from 1.9 to 1.0 us per pass at 1024^2, the sweeps grew from 7.0 to 7.7 us, the pass stayed at 9.9-10.1 us.)
+template <int T, int R, int NW, bool FMA, bool WALL>
+__device__ __forceinline__ void wgs_sweeps(double2 (&xr)[R], const WgsCoef<R> &k, const double2 (&bb)[WALL ? R : 1],
+                                           double2 (&edge)[2][NW][2][64], int &par, const int wave, const int lane,
+                                           const int w0, const int ry0, const int ry1, const int row_lo, const int row_hi,
+                                           const double omw)
+{
+    const double2 zero = make_double2(0.0, 0.0);
+    auto b_of = [&](const int r) __attribute__((always_inline)) { return WALL ? bb[WALL ? r : 0] : zero; };
+    auto one = [&](const int r, const double2 n_, const double2 c_, const double2 s_) __attribute__((always_inline)) {
+        const double2 c01[1] = {k.c0[r]}, aE1[1] = {k.aE[r]}, aS1[1] = {k.aS[r]}, aN1[1] = {r == 0 ? k.aN0 : k.aS[r == 0 ? 0 : r - 1]};
+        const double aW1[1] = {k.aW0[r]};
+        const double2 b1[1] = {b_of(r)};
+        const double2 n1[1] = {n_}, c1[1] = {c_}, s1[1] = {s_};
+        double2 o[1];
+        wgs_rows<1, FMA>(c01, aW1, aE1, aS1, aN1, b1, n1, c1, s1, omw, o);
+        return o[0];
+    };
+    auto two = [&](const int ra, const int rb, const double2 na, const double2 ca, const double2 sa, const double2 nb,
+                   const double2 cb, const double2 sb, double2 &oa, double2 &ob) __attribute__((always_inline)) {
+        const double2 c02[2] = {k.c0[ra], k.c0[rb]}, aE2[2] = {k.aE[ra], k.aE[rb]}, aS2[2] = {k.aS[ra], k.aS[rb]};
+        const double2 aN2[2] = {ra == 0 ? k.aN0 : k.aS[ra == 0 ? 0 : ra - 1], k.aS[rb - 1]};
+        const double aW2[2] = {k.aW0[ra], k.aW0[rb]};
+        const double2 b2[2] = {b_of(ra), b_of(rb)};
+        const double2 n2[2] = {na, nb}, c2[2] = {ca, cb}, s2[2] = {sa, sb};
+        double2 o[2];
+        wgs_rows<2, FMA>(c02, aW2, aE2, aS2, aN2, b2, n2, c2, s2, omw, o);
+        oa = o[0];
+        ob = o[1];
+    };
+#pragma unroll 1
+    for (int t = 1; t <= T; ++t) {
+        // level t is needed on [ry0 - (T - t), ry1 + (T - t)) inside the mesh
+        const int need_lo = max(ry0 - (T - t), row_lo), need_hi = min(ry1 + (T - t), row_hi);
+        edge[par][wave][0][lane] = xr[0];
+        edge[par][wave][1][lane] = xr[R - 1];
+        const bool any = w0 + R > need_lo && w0 < need_hi;
+        const bool full = w0 >= need_lo && w0 + R <= need_hi;
+        if (full) {
+            const double2 old1 = xr[1], oldp = xr[R - 2];
+            double2 prev = xr[0];
+#pragma unroll
+            for (int r = 1; r + 1 <= R - 2; r += 2) {
+                const double2 ca = xr[r], cb = xr[r + 1];
+                two(r, r + 1, prev, ca, cb, ca, cb, xr[r + 2], xr[r], xr[r + 1]);
+                prev = cb;
+            }
+            if constexpr ((R - 2) % 2 == 1) xr[R - 2] = one(R - 2, prev, xr[R - 2], xr[R - 1]);
+            __syncthreads();
+            const double2 top = (wave > 0) ? edge[par][wave - 1][1][lane] : zero;
+            const double2 bot = (wave < NW - 1) ? edge[par][wave + 1][0][lane] : zero;
+            two(0, R - 1, top, xr[0], old1, oldp, xr[R - 1], bot, xr[0], xr[R - 1]);
+        } else if (any) {
+            const double2 old1 = xr[1], oldp = xr[R - 2];
+            double2 prev = xr[0];
+#pragma unroll
+            for (int r = 1; r <= R - 2; ++r) {
+                const double2 cur = xr[r];
+                const int rr = w0 + r;
+                if (rr >= need_lo && rr < need_hi) xr[r] = one(r, prev, cur, xr[r + 1]);
+                prev = cur;
+            }
+            __syncthreads();
+            const double2 top = (wave > 0) ? edge[par][wave - 1][1][lane] : zero;
+            const double2 bot = (wave < NW - 1) ? edge[par][wave + 1][0][lane] : zero;
+            if (w0 >= need_lo && w0 < need_hi) xr[0] = one(0, top, xr[0], old1);
+            if (w0 + R - 1 >= need_lo && w0 + R - 1 < need_hi) xr[R - 1] = one(R - 1, oldp, xr[R - 1], bot);
+        } else {
+            __syncthreads();
+        }
+        par ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Resident form: when ALL tiles of the context are on the chip at once (one tile per workgroup, every workgroup
 // resident: one 1024^2 image is 234 tiles on 256 CUs), the launch need not end after T sweeps.  A workgroup keeps its
 // tile's MATRIX ROWS and its OWNED CELLS in registers over `npass` passes and exchanges only the halo with its (up to 8)
@@ -524,11 +673,16 @@ __device__ __forceinline__ void wgl_sweeps(double2 (&xr)[R], const unsigned *cod
 //   boundary orders it after everything before.  `base` grows by npass from launch to launch, so stale flags are always
 //   smaller than anything waited for.
 // Forward progress: the host launches at most as many workgroups as the occupancy query says are co-resident and never
-// two resident kernels of one process on one device at a time (api_solve.hip; or hipLaunchCooperativeKernel, tuning
-// tb_launch = 2), and every wait is bounded -- a lane that has polled for WGR_TIMEOUT of the 100 MHz wall clock, or that
-// sees *abort_flag set, raises *abort_flag and its workgroup returns; so does, within one poll, every workgroup waiting
-// anywhere.  The host checks the flag at its next synchronisation and fails the call.  (stall_tile >= 0 makes that tile
-// leave without publishing -- the tests' way to exercise this path.)
+// two resident kernels of one process on one device at a time (api_solve.hip), and every wait is bounded -- a lane that
+// has polled for WGR_TIMEOUT of the 100 MHz wall clock, or that sees *abort_flag set, raises *abort_flag and its workgroup
+// returns; so does, within one poll, every workgroup waiting anywhere.  The host checks the flag at its next
+// synchronisation, restores the field the interval started from and redoes it with one launch per pass (resident_check).
+// (stall_tile >= 0 makes that tile leave without publishing -- the tests' way to exercise this path.)
+// (hipLaunchCooperativeKernel, which would make the runtime vouch for co-residency, was offered as tb_launch = 2 in round 2
+// and is gone: with several host threads launching cooperatively the process died in libhsa-runtime64 under the HIP
+// runtime's own exit handler, deff2d --devices 0,0,0, while the plain launch that this library bounds itself exited
+// cleanly -- the library's own objects were not involved, the cooperative path bypasses the event chain -- and with the
+// fallback above the plain launch needs no such guarantee.)
 // Same arithmetic, same tiles, same results bit for bit as npass launches of k_sweep_wgtile.
 constexpr unsigned long long WGR_TIMEOUT = 200000000ull;       // 2 s
 constexpr int WGR_FLAG_STRIDE = 64;                            // unsigneds between two tiles' flags: one 256-byte block each, so that
@@ -561,10 +715,12 @@ __device__ __forceinline__ void wgr_st2(__amdgpu_buffer_rsrc_t r, unsigned voff,
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, WGR_SC1);
 }
 
-// TALL = the 16-wave form above (matrix rows looked up in every sweep); otherwise the 8-wave form with the matrix rows in
-// registers.  The exchange protocol is the same code for both.
-template <int T, int R, bool FMA, bool GUARD, bool TALL = false, bool SYM = false>
-__global__ __launch_bounds__((TALL ? WGL_WAVES : WGT_WAVES) * 64, (TALL ? 4 : 2)) void k_sweep_wgres(const double *__restrict__ lut_g,
+// Forms of a resident tile; the exchange protocol is the same code for all of them.
+constexpr int WGF_COEF = 0;     // 8 waves, full matrix rows in registers (20 VGPRs per tile row): any dictionary
+constexpr int WGF_TALL = 1;     // 16 waves, field in registers, codes in LDS, matrix rows looked up in every sweep
+constexpr int WGF_SYM = 2;      // NW waves, link-symmetric matrix rows in registers (14 VGPRs per tile row), unguarded systems
+template <int T, int R, int NW, bool FMA, bool GUARD, int FORM, bool SYM>
+__device__ __forceinline__ void wgres_body(const double *__restrict__ lut_g,
                                                                    const uint16_t *__restrict__ code, double *xa,
                                                                    double *xb, int nx, int ny, int img_stride,
                                                                    int dom_lo, int own_lo, int own_h, int cpi, int ly,
@@ -575,9 +731,11 @@ __global__ __launch_bounds__((TALL ? WGL_WAVES : WGT_WAVES) * 64, (TALL ? 4 : 2)
                                                                    unsigned xbytes, int stall_tile,
                                                                    unsigned long long *__restrict__ stamps)
 {
-    constexpr int NW = TALL ? WGL_WAVES : WGT_WAVES;
-    static_assert(T >= 1 && T <= 8 && R >= 4, "unsupported tile");
+    constexpr bool TALL = FORM == WGF_TALL;
+    static_assert(T >= 1 && T <= 8 && R >= 3, "unsupported tile");
     static_assert(NW * R - 2 * T >= 1, "tile owns no row");
+    static_assert(FORM != WGF_SYM || !GUARD, "the symmetric form has no guarded variant");
+    static_assert(LUT_PLANES * LUT_MAX_ROWS <= 6 * NW * 64, "dictionary fetch assumes <= 6 doubles per thread");
     constexpr int HW = (T + 1) & ~1;
     constexpr int WOUT = TB_COLS - 2 * HW;
 
@@ -652,10 +810,11 @@ __global__ __launch_bounds__((TALL ? WGL_WAVES : WGT_WAVES) * 64, (TALL ? 4 : 2)
 
     auto passes = [&](auto wall_tag) __attribute__((always_inline)) {
         constexpr bool WALL = decltype(wall_tag)::value;
-        // the 8-wave form looks its matrix rows up ONCE per launch
-        WgtCoef k[TALL ? 1 : R];
+        // the coefficient-resident forms look their matrix rows up ONCE per launch
+        WgtCoef k[FORM == WGF_COEF ? R : 1];
+        WgsCoef<FORM == WGF_SYM ? R : 1> ks;
         double2 bb[(WALL && !TALL) ? R : 1];
-        if constexpr (!TALL) {
+        if constexpr (FORM == WGF_COEF) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 double2 b_;
@@ -663,6 +822,7 @@ __global__ __launch_bounds__((TALL ? WGL_WAVES : WGT_WAVES) * 64, (TALL ? 4 : 2)
                 if constexpr (WALL) bb[r] = b_;
             }
         }
+        if constexpr (FORM == WGF_SYM) wgs_lookup<R, WALL>(lut, cc, ks, bb);
         const __amdgpu_buffer_rsrc_t ra = wgr_rsrc(xa, xbytes), rb = wgr_rsrc(xb, xbytes);
         // what a tile exchanges with its neighbours: its halo (read) and the rim of its owned cells (written) -- the owned
         // cells themselves never leave the registers between two passes of a launch
@@ -707,6 +867,7 @@ __global__ __launch_bounds__((TALL ? WGL_WAVES : WGT_WAVES) * 64, (TALL ? 4 : 2)
                 st[4 * p + 1] = wall_clock64();
             }
             if constexpr (TALL) wgl_sweeps<T, R, FMA, GUARD, WALL, SYM>(xr, codes_lds + wave * R * 64 + lane, lut, edge, par, wave, lane, w0, ry0, ry1, row_lo, row_hi, omw);
+            else if constexpr (FORM == WGF_SYM) wgs_sweeps<T, R, NW, FMA, WALL>(xr, ks, bb, edge, par, wave, lane, w0, ry0, ry1, row_lo, row_hi, omw);
             else wgt_sweeps<T, R, FMA, GUARD, WALL>(xr, k, bb, edge, par, wave, lane, w0, ry0, ry1, row_lo, row_hi, omw, nullptr);
             if (st && p < 3) st[4 * p + 2] = wall_clock64();
             if (alone && !last) continue;                          // workgroup-uniform
@@ -732,6 +893,43 @@ __global__ __launch_bounds__((TALL ? WGL_WAVES : WGT_WAVES) * 64, (TALL ? 4 : 2)
     };
     if (wall) passes(TbTag<true>{});
     else passes(TbTag<false>{});
+}
+
+// TALL = the 16-wave form (matrix rows looked up in every sweep); otherwise the 8-wave form with the matrix rows in registers.
+template <int T, int R, bool FMA, bool GUARD, bool TALL = false, bool SYM = false>
+__global__ __launch_bounds__((TALL ? WGL_WAVES : WGT_WAVES) * 64, (TALL ? 4 : 2)) void k_sweep_wgres(const double *__restrict__ lut_g,
+                                                                   const uint16_t *__restrict__ code, double *xa,
+                                                                   double *xb, int nx, int ny, int img_stride,
+                                                                   int dom_lo, int own_lo, int own_h, int cpi, int ly,
+                                                                   const uint8_t *__restrict__ active, int ntx, int gy,
+                                                                   int xmajor, int allb, int nrows, int shift,
+                                                                   double omw, int npass, unsigned *flags,
+                                                                   unsigned base, unsigned *abort_flag,
+                                                                   unsigned xbytes, int stall_tile,
+                                                                   unsigned long long *__restrict__ stamps)
+{
+    static_assert(R >= 4, "unsupported tile");
+    wgres_body<T, R, (TALL ? WGL_WAVES : WGT_WAVES), FMA, GUARD, (TALL ? WGF_TALL : WGF_COEF), SYM>(
+        lut_g, code, xa, xb, nx, ny, img_stride, dom_lo, own_lo, own_h, cpi, ly, active, ntx, gy, xmajor, allb, nrows, shift, omw,
+        npass, flags, base, abort_flag, xbytes, stall_tile, stamps);
+}
+
+// The link-symmetric form: 12 waves per workgroup = 3 per SIMD (168 VGPRs), R rows per wave.
+template <int T, int R, bool FMA>
+__global__ __launch_bounds__(WGS_WAVES * 64, 3) void k_sweep_wgsym(const double *__restrict__ lut_g,
+                                                                   const uint16_t *__restrict__ code, double *xa,
+                                                                   double *xb, int nx, int ny, int img_stride,
+                                                                   int dom_lo, int own_lo, int own_h, int cpi, int ly,
+                                                                   const uint8_t *__restrict__ active, int ntx, int gy,
+                                                                   int xmajor, int allb, int nrows, int shift,
+                                                                   double omw, int npass, unsigned *flags,
+                                                                   unsigned base, unsigned *abort_flag,
+                                                                   unsigned xbytes, int stall_tile,
+                                                                   unsigned long long *__restrict__ stamps)
+{
+    wgres_body<T, R, WGS_WAVES, FMA, false, WGF_SYM, true>(
+        lut_g, code, xa, xb, nx, ny, img_stride, dom_lo, own_lo, own_h, cpi, ly, active, ntx, gy, xmajor, allb, nrows, shift, omw,
+        npass, flags, base, abort_flag, xbytes, stall_tile, stamps);
 }
 
 }  // namespace deff

@@ -81,6 +81,12 @@ class Solver:
             out[key] = v.value
         return out
 
+    def plan_value(self, key):
+        """One key of deff_get_plan, e.g. "tb_fallbacks" (resident intervals that were redone with one launch per pass)."""
+        v = C.c_int()
+        check(self._L.deff_get_plan(self._ctx, key.encode(), C.byref(v)))
+        return v.value
+
     # -- image / assembly -------------------------------------------------
     def set_image(self, pix, ampX=1, ampY=1):
         pix = np.ascontiguousarray(pix, dtype=np.uint8)

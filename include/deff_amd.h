@@ -84,7 +84,9 @@ int deff_get_kernel(const deff_ctx *ctx, int *kernel_in_use);
  * "tb_impl" (1 streaming, 2 workgroup tiles), "tb_R", "tb_NW" (8 or 16 waves per tile: 16 = tall resident tiles),
  * "tb_launch" (workgroup tiles whose tiles all fit the chip
  *   run every pass between two checks in ONE launch, neighbouring tiles synchronised by flags: 1 = one launch per
- *   pass instead, 2 = through hipLaunchCooperativeKernel), "flux_reduce", and
+ *   pass instead; a resident launch that cannot make progress -- another process holds part of the GPU -- gives up
+ *   after a bounded wait, the interval is redone with one launch per pass and the context stays in that mode:
+ *   deff_get_plan "tb_fallbacks"), "flux_reduce", and
  *   "fma" = 1: contracted arithmetic -- the reference's expressions (cuh:74-89, cuh:1957) with each
  *   product fused into the following add, as nvcc's default -fmad=true / gcc -ffp-contract=fast compile
  *   them; bit-identical to the oracle's fma build, not to the default (written-order) arithmetic.
@@ -92,7 +94,8 @@ int deff_get_kernel(const deff_ctx *ctx, int *kernel_in_use);
 int deff_set_tuning(deff_ctx *ctx, const char *key, int value);
 /* what the last launch plan of the temporally blocked kernel chose: "tb_T", "tb_LY" (rows per chunk),
  * "tb_strips", "tb_chunks_per_image", "tb_blocks" (workgroups launched), "tb_impl", "tb_R", "tb_resident" (1: the
- * passes of a batch run as one resident launch); 0 before any sweep */
+ * passes of a batch run as one resident launch), "tb_fallbacks" (resident intervals that gave up and were redone with
+ * one launch per pass); 0 before any sweep */
 int deff_get_plan(deff_ctx *ctx, const char *key, int *value);
 
 /* ---- image -> phases: replaces the mask->D loops cuh:1988-2000 (2-phase),

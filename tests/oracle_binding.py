@@ -173,12 +173,13 @@ def fracts_3d(D, DCS, DCF):
     return s.value, l.value
 
 
-def solve_3phase(pix, DCS, DCF, DCG, CL, CR, tol, max_iter, flavour=None):
+def solve_3phase(pix, DCS, DCF, DCG, CL, CR, tol, max_iter, flavour=None, precond_max_iter=1000000):
     """SingleSim3Phase / BatchSim3Phase, cuh:1316-1633 (preCond = true, cuh:1443), on the oracle:
     Grid from pixels > 200 + FloodFill; gas diffusivity ramped 10, 100, ... < DCG with
     tolerance x10 and MAX_ITER 1e6 (JacobiGPUPreCond), each stage warm-started; then the real
-    DCG with the user's tolerance (JacobiGPU).  Returns dict(stage_sweeps, deff, conv, SVF, LVF,
-    field, grid, path)."""
+    DCG with the user's tolerance (JacobiGPU).  `precond_max_iter` replaces the reference's literal 1e6
+    (cuh:1503) so that a large image fits an oracle run (deff2d --precond-maxiter is the same knob).
+    Returns dict(stage_sweeps, deff, conv, SVF, LVF, field, grid, path)."""
     ny, nx = pix.shape
     grid, path = floodfill((pix > 200).astype(np.uint32))
     x = linear_guess(nx, ny, CL, CR)
@@ -187,7 +188,7 @@ def solve_3phase(pix, DCS, DCF, DCG, CL, CR, tol, max_iter, flavour=None):
     while g < DCG:                                   # cuh:1492
         D = fill_D_3phase(pix, DCF, DCS, g)
         A, b = discretize(D, CL, CR, grid=grid)
-        it, _, _, x, _, _ = jacobi(A, b, x, D, CL, CR, tol * 10, 1000000, flavour=flavour)
+        it, _, _, x, _, _ = jacobi(A, b, x, D, CL, CR, tol * 10, precond_max_iter, flavour=flavour)
         stages.append(it)
         g = g * 10
     D = fill_D_3phase(pix, DCF, DCS, DCG)

@@ -330,6 +330,37 @@ def test_driver_3phase_as_shipped(built, tmp_path, recorded):
 
 
 @pytest.mark.gpu
+def test_driver_3phase_as_shipped_on_its_own_image(built, tmp_path):
+    """The reference's shipped input.txt on the image it names, 00042.jpg (1002 x 2007, three grey levels, ~329 k pixels
+    exactly at 150; input.txt:2-18, SingleSim3Phase cuh:1316-1633): flood fill with the seeded right column, six DCG
+    continuation stages and the final solve.  The oracle ran this flow ONCE in the authoring container with every stage
+    capped (tests/golden/make_img00042_golden.py -> img00042_3phase_capped.json; the uncapped run is hours of one core);
+    deff2d must reproduce stage sweeps, Deff, conv, volume fractions, PathFlag and the FP64 field bit for bit."""
+    import hashlib
+    gold = json.load(open(os.path.join(GOLDEN, "img00042_3phase_capped.json")))
+    cap = gold["options"]["MaxIter"]
+    shutil.copy(os.path.join(GOLDEN, "00042.jpg"), tmp_path / "00042.jpg")
+    _write_input(tmp_path / "input.txt", Phases=3, Ds=0, Df=1, Dg=1237500, MeshAmpX=1, MeshAmpY=1,
+                 InputName="00042.jpg", CR=1, CL=0, OutputName="singleTest.csv", printCMap=0, CMapName="CMAP_00042.csv",
+                 Convergence="1e-5", MaxIter=cap, Verbose=1, RunBatch=0, NumImages=500)
+    r = subprocess.run([EXE, "--json", "res.json", "--field-bin", "field", "--precond-maxiter", str(gold["options"]["precond_maxiter"])],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    res = json.load(open(tmp_path / "res.json"))["results"][0]
+    assert res["stage_iterations"] == gold["stage_sweeps"]
+    assert res["Deff"] == gold["deff"] and res["converge"] == gold["conv"]
+    assert res["SVF"] == gold["SVF"] and res["LVF"] == gold["LVF"] and bool(res["PathFlag"]) == gold["path"]
+    H, W = gold["shape"]
+    assert res["nElements"] == H * W
+    x = np.fromfile(tmp_path / f"field_00000_{W}x{H}.f64", dtype=np.float64).reshape(H, W)
+    for key, v in gold["field_probe"].items():
+        i, j = map(int, key.split(","))
+        assert x[i, j] == v, (key, x[i, j], v)
+    assert hashlib.sha256(x.tobytes()).hexdigest() == gold["field_sha256"]
+    assert "Pre-Cond Stage 6: DCG = 1.000e+06" in r.stdout
+
+
+@pytest.mark.gpu
 def test_driver_batch_groups_images(built, tmp_path, oracle):
     """RunBatch over 7 images of 96x64 solved in stacked groups of 3: every row equals the oracle's
     one-image result, whatever the grouping."""

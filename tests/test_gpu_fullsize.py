@@ -195,3 +195,36 @@ def test_config2_to_tolerance_regression(pkg):
     assert d == r.deff_raw
     # Deff decreases monotonically from the linear guess's value on this medium
     assert all(trace[k + 1][1] < trace[k][1] for k in range(1, len(trace) - 1))
+
+
+@pytest.mark.parametrize("B,force", [(16, "planner"), (64, "streaming")])
+def test_config5_stacks_of_1024_vs_oracle(pkg, oracle, B, force):
+    """BASELINE config #5's SHAPE on the kernels that do its work (the loop of BatchSim, cuh:1843-2054, stacked): a stack
+    of B synthetic 1024^2 images (images 0..B-1 of the generator) swept 3T + 3 = 27 times by temporally blocked passes
+    -- 16 images on the form the planner picks, 64 images (the stack size of tools/measure_config5.py) forced onto the
+    streaming form -- and EVERY image compared with the oracle's one-image run (~1 s of one core per image)."""
+    n, nsw = 1024, 27
+    with pkg.Solver(n, n, nimg=B, kernel="matfree_tb") as s:
+        if force == "streaming":
+            s.set_tuning("tb_impl", 1)
+        s.synth_image(12345, 0)
+        pix = s.get_image().reshape(B, n, n)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(nsw)
+        p = s.plan()
+        assert s.kernel_in_use() == "matfree_tb" and p["tb_T"] == 8
+        if force == "streaming":
+            assert p["tb_impl"] == 1
+        got = s.get_field().reshape(B, n, n)
+        deffs, MFL, MFR = s.flux()
+    x0 = oracle.linear_guess(n, n, 0.0, 1.0)
+    for k in range(B):
+        assert np.array_equal(pix[k], oracle.synth_mask(n, n, 12345, k))
+        D = oracle.fill_D_2phase(pix[k], 1.0, 1e-3)
+        A, b = oracle.discretize(D, 0.0, 1.0)
+        want = oracle.sweeps(A, b, x0, nsw)
+        assert_same(got[k], want)
+        d, mfl, mfr = oracle.flux_deff(want, D, 0.0, 1.0)
+        assert deffs[k] == d
+        assert np.array_equal(MFL[k * n:(k + 1) * n], mfl) and np.array_equal(MFR[k * n:(k + 1) * n], mfr)

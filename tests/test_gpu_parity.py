@@ -132,8 +132,10 @@ def test_launch_plan_is_reported(pkg):
         s.init_linear(0.0, 1.0)
         s.sweeps(16)
         p = s.plan()
-        # ONE image below 4 Mi cells: workgroup tiles, 8 sweeps per pass, 8 waves x 7 rows, every tile resident at once
-        assert p["tb_impl"] == 2 and p["tb_T"] == 8 and p["tb_R"] == 7 and p["tb_strips"] == 9
+        # ONE image below 4 Mi cells: workgroup tiles, 8 sweeps per pass, every tile resident at once -- the native assembly
+        # is link-symmetric, so 12 waves x 5 rows with the matrix rows in registers (k_sweep_wgsym)
+        assert p["tb_impl"] == 2 and p["tb_T"] == 8 and (p["tb_NW"], p["tb_R"]) == (12, 5) and p["tb_strips"] == 9
+        assert p["tb_resident"] == 1 and p["tb_sym"] == 1
         assert p["tb_strips"] * p["tb_chunks_per_image"] <= 256 and p["tb_LY"] * p["tb_chunks_per_image"] >= 1024
         s.set_tuning("tb_impl", 1)
         s.set_tuning("tb_T", 8)

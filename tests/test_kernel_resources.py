@@ -96,6 +96,21 @@ def test_tall_resident_kernel_fits_four_waves_per_simd(usage):
     assert seen == set(budget)
 
 
+def test_symmetric_tile_kernel_fits_three_waves_per_simd(usage):
+    """k_sweep_wgsym<8, R, FMA>: 12 waves per workgroup = 3 per SIMD = 168 VGPRs, symmetric matrix rows in registers (14 VGPRs
+    per tile row); R = 3, 4, 5 without any scratch (R = 6 would spill inside the sweep loop and is not instantiated);
+    LDS = dictionary + 48 KiB mailbox."""
+    seen = set()
+    for name, u in usage.items():
+        m = re.match(r"_ZN4deff13k_sweep_wgsymILi8ELi(\d+)ELb[01]EEE", name)
+        if not m:
+            continue
+        seen.add(int(m.group(1)))
+        assert u["Occupancy"] >= 3 and u["VGPRs"] <= 168 and u["AGPRs"] == 0 and u["ScratchSize"] == 0, (name, u)
+        assert u["LDS"] <= 80 * 1024, (name, u)
+    assert seen == {3, 4, 5}
+
+
 def test_single_sweep_kernels_are_light(usage):
     for prefix in ("_ZN4deff16k_sweep_explicitI", "_ZN4deff15k_sweep_matfreeI", "_ZN4deff14k_sweep_scalarI"):
         for name, u in kernels(usage, prefix).items():
