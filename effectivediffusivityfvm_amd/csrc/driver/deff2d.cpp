@@ -9,7 +9,7 @@
 // --field-bin dumps the FP64 concentration field.
 //
 //   deff2d [input.txt] [--device N | --devices 0,1,..] [--json results.json] [--field-bin prefix] [--batch-size B]
-//          [--progress file] [--arith reference|contracted] [--precond-maxiter N]
+//          [--progress file] [--arith reference|contracted] [--precond-maxiter N] [--prefetch-threads K]
 // --arith contracted: products fused into adds the way a compiler contracts the reference's expressions
 // (kernels_sweep.hpp); default is the reference's written operation order.
 //
@@ -109,6 +109,8 @@ static int g_contracted = 0;       // --arith contracted: deff_set_tuning(ctx, "
 // MAX_ITER of the 3-phase continuation stages: the reference's literal 1e6 (cuh:1503).  --precond-maxiter N replaces it so
 // that a capped run of a large image fits a CPU oracle run (tests/golden/make_img00042_golden.py); not an input.txt key.
 static int64_t g_precond_maxiter = 1000000;
+// threads that prepare images ahead of each worker's solver (2-phase batch mode), see Prefetcher
+static int g_prefetch_threads = 2;
 
 struct Session {                   // one solver context, re-created only when the mesh / batch size changes
     deff_ctx *ctx = nullptr;
@@ -443,18 +445,24 @@ struct Prepared {
     int path = 0;
 };
 
-// One per worker: a host thread that takes the next unsolved image indices from the shared counter and prepares them
-// (file read, JPEG decode, porosity, flood fill) a few images AHEAD of the solver, so that the GPU does not wait for the
-// host between two launches when a slot is refilled (12 288 images of 128^2: ~0.2 ms of host work per image, ~5 images per
+// One per worker: host threads that take the next unsolved image indices from the shared counter and prepare them (file
+// read, JPEG decode, porosity, flood fill) a few images AHEAD of the solver, so that the GPU does not wait for the host
+// between two launches when a slot is refilled (12 288 images of 128^2: ~0.2 ms of host work per image, ~5 images per
 // check interval of 25 ms).  The look-ahead is short, so that several workers still share the end of a dataset evenly.
+// One thread prepares ~140 images of 1024^2 per second (7 ms each: decode, porosity, flood fill); BASELINE config #5 needs
+// ~126 per second and worker to keep a GPU busy, so large images get `threads` > 1 (--prefetch-threads; images may then
+// reach the solver out of index order, which the results table does not care about: rows land by index).
 class Prefetcher {
 public:
-    Prefetcher(Shared *sh, size_t depth) : sh_(sh), depth_(depth), th_([this] { run(); }) {}
+    Prefetcher(Shared *sh, size_t depth, int threads = 1) : sh_(sh), depth_(depth), running_(threads < 1 ? 1 : threads)
+    {
+        for (int t = 0; t < running_; ++t) th_.emplace_back([this] { run(); });
+    }
     ~Prefetcher()
     {
         { std::lock_guard<std::mutex> lock(mu_); stop_ = true; }
         cv_.notify_all();
-        th_.join();
+        for (std::thread &t : th_) t.join();
     }
     Prepared pop()
     {
@@ -468,6 +476,13 @@ public:
     }
 
 private:
+    // the last thread to run out of work appends the end marker: every prepared image is in the queue before it
+    void leave()
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        if (--running_ == 0) q_.push_back(Prepared());
+        cv_.notify_all();
+    }
     void run()
     {
         const Options &o = *sh_->o;
@@ -480,23 +495,20 @@ private:
             Prepared p;
             int k;
             do { k = sh_->next_index->fetch_add(1); } while (k < sh_->count && (*sh_->done)[(size_t)k]);
-            if (k < sh_->count && !sh_->failed->load()) {
-                if (!load_image(sh_->name(k), &p.im)) {
-                    *sh_->failed = true;
-                } else {
-                    p.k = k;
-                    p.porosity = porosity_of(p.im);
-                    std::vector<unsigned int> grid = grid_of(p.im, o, 150);
-                    if (deff_flood_fill(grid.data(), p.im.W * o.MeshIncreaseX, p.im.H * o.MeshIncreaseY, &p.path) != DEFF_OK) {
-                        *sh_->failed = true;
-                        p.k = -1;
-                    }
-                }
+            if (k >= sh_->count || sh_->failed->load()) return leave();
+            if (!load_image(sh_->name(k), &p.im)) {
+                *sh_->failed = true;
+                return leave();
             }
-            const bool end = p.k < 0;
+            p.k = k;
+            p.porosity = porosity_of(p.im);
+            std::vector<unsigned int> grid = grid_of(p.im, o, 150);
+            if (deff_flood_fill(grid.data(), p.im.W * o.MeshIncreaseX, p.im.H * o.MeshIncreaseY, &p.path) != DEFF_OK) {
+                *sh_->failed = true;
+                return leave();
+            }
             { std::lock_guard<std::mutex> lock(mu_); q_.push_back(std::move(p)); }
             cv_.notify_all();
-            if (end) return;
         }
     }
     Shared *sh_;
@@ -505,7 +517,8 @@ private:
     std::condition_variable cv_;
     std::deque<Prepared> q_;
     bool stop_ = false;
-    std::thread th_;                                             // last member: started when everything else exists
+    int running_;
+    std::vector<std::thread> th_;                                // last member: started when everything else exists
 };
 
 struct StreamState {
@@ -641,12 +654,13 @@ int main(int argc, char **argv)
             else if (v == "reference" || v == "plain") g_contracted = 0;
             else { std::fprintf(stderr, "deff2d: --arith takes 'reference' or 'contracted'\n"); return 2; }
         }
+        else if (s == "--prefetch-threads" && a + 1 < argc) g_prefetch_threads = std::atoi(argv[++a]);
         else if (s == "--precond-maxiter" && a + 1 < argc) {
             g_precond_maxiter = (int64_t)std::strtod(argv[++a], nullptr);
             if (g_precond_maxiter < 1) { std::fprintf(stderr, "deff2d: --precond-maxiter must be >= 1\n"); return 2; }
         }
         else if (s == "-h" || s == "--help") {
-            std::printf("usage: deff2d [input.txt] [--device N] [--json results.json] [--field-bin prefix] [--batch-size B] [--devices 0,1,...] [--progress file] [--arith reference|contracted] [--precond-maxiter N]\n");
+            std::printf("usage: deff2d [input.txt] [--device N] [--json results.json] [--field-bin prefix] [--batch-size B] [--devices 0,1,...] [--progress file] [--arith reference|contracted] [--precond-maxiter N] [--prefetch-threads K]\n");
             return 0;
         } else if (!s.empty() && s[0] != '-') input = s;
         else { std::fprintf(stderr, "deff2d: unknown argument %s\n", s.c_str()); return 2; }
@@ -693,7 +707,7 @@ int main(int argc, char **argv)
     auto stream_worker = [&](int dev) {
         StreamState st;
         st.sh = &shared;
-        Prefetcher source(&shared, 8);
+        Prefetcher source(&shared, 8, g_prefetch_threads);
         st.source = &source;
         for (;;) {
             if (!st.have_pending) {                              // first image of the next stream fixes its size

@@ -1,4 +1,4 @@
-// jpeg_gray.hpp -- baseline JPEG decoder for single-component (grayscale) images.
+// jpeg_gray.hpp -- JPEG decoder (baseline, extended sequential and progressive Huffman) for single-component (grayscale) images.
 //
 // The reference loads its input with stb_image v2.26, `stbi_load(name, &w, &h, &n, 1)`
 // (Deff2DGPU/Deff2D.cuh:342, cuh:377), and requires n == 1 (cuh:1665, cuh:1890).  Phase
@@ -6,14 +6,18 @@
 // section 5 records that libjpeg differs from stb_image by +-1 on thousands of pixels of the
 // reference's 00042.jpg and flips several hundred across the 150 threshold.  stb_image.h is
 // not redistributed here; this is an independent decoder for the files the reference accepts
-// (baseline / extended-sequential Huffman, 8-bit, one component) that follows the same
+// (baseline / extended-sequential / progressive Huffman, 8-bit, one component) that follows the same
 // arithmetic so that it produces the same bytes:
 //   * coefficients are dequantised into 16-bit storage (product truncated to int16),
 //   * the inverse DCT is the LL&M "islow" scheme of the IJG library (jidctint) in 12-bit
 //     fixed point: column pass keeps 2 extra bits (+512, >>10), row pass removes 17 bits with
 //     rounding (+65536) and folds in the +128 level shift, then clamps to 0..255.
+//   * progressive files (SOF2, ITU T.81 annex G: spectral selection and successive approximation) accumulate their
+//     coefficients over the scans in the same 16-bit storage -- point transforms as shifts truncated to int16 -- and are
+//     dequantised (product truncated to int16) and inverse-transformed once, after the last scan, like stb_image.h:3006-3025.
 // Multi-component files are recognised (ncomp is reported) but not decoded: the reference
-// rejects them too.  Progressive and arithmetic-coded files are rejected with a message.
+// rejects them too.  Arithmetic-coded and lossless files are rejected with a message, and so are PNG / BMP files, which
+// the reference's stbi_load would read (stb_image.h:1094-1097): convert those to JPEG.
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -169,24 +173,143 @@ inline void idct_block(const int16_t c[64], uint8_t *out, int stride)
     }
 }
 
+// One scan of a progressive one-component image over all its blocks (T.81 G.1.2): DC first / refinement (Ss = 0) or AC
+// first / refinement (Ss > 0) with end-of-band runs.  `coef` holds 64 int16 per block, natural (de-zigzagged) order.
+inline bool progressive_scan(BitReader &br, int16_t *coef, size_t nblocks, const Huffman *hdc, const Huffman *hac, int Ss, int Se,
+                             int Ah, int Al, int restart, std::string &err)
+{
+    int64_t pred = 0;
+    int eobrun = 0, todo = restart;
+    const int16_t bit = (int16_t)(1 << Al);
+    // successive-approximation correction of an already non-zero coefficient (G.1.2.3)
+    auto refine = [&](int16_t &c) {
+        if (br.bit() && (c & bit) == 0) c = (int16_t)(c > 0 ? c + bit : c - bit);
+    };
+    for (size_t blk = 0; blk < nblocks; ++blk) {
+        int16_t *d = coef + blk * 64;
+        if (Ss == 0) {
+            if (Ah == 0) {
+                const int t = decode_symbol(br, *hdc);
+                if (t < 0 || t > 15) { err = "corrupt DC code"; return false; }
+                pred += t ? extend(br.bits(t), t) : 0;
+                d[0] = (int16_t)(pred * (1 << Al));
+            } else if (br.bit()) {
+                d[0] = (int16_t)(d[0] + bit);
+            }
+        } else if (Ah == 0) {
+            if (eobrun) {
+                --eobrun;
+            } else {
+                for (int k = Ss; k <= Se;) {
+                    const int rs = decode_symbol(br, *hac);
+                    if (rs < 0) { err = "corrupt AC code"; return false; }
+                    const int r = rs >> 4, sz = rs & 15;
+                    if (sz == 0) {
+                        if (r < 15) {                              // end of band for this block and eobrun more
+                            eobrun = (1 << r) - 1;
+                            if (r) eobrun += br.bits(r);
+                            break;
+                        }
+                        k += 16;
+                    } else {
+                        k += r;
+                        if (k > 63) { err = "corrupt block"; return false; }
+                        d[ZIGZAG[k++]] = (int16_t)(extend(br.bits(sz), sz) * (1 << Al));
+                    }
+                }
+            }
+        } else {
+            if (eobrun) {
+                --eobrun;
+                for (int k = Ss; k <= Se; ++k)
+                    if (d[ZIGZAG[k]] != 0) refine(d[ZIGZAG[k]]);
+            } else {
+                for (int k = Ss; k <= Se;) {
+                    const int rs = decode_symbol(br, *hac);
+                    if (rs < 0) { err = "corrupt AC code"; return false; }
+                    int r = rs >> 4;
+                    const int sz = rs & 15;
+                    int16_t val = 0;
+                    if (sz == 0) {
+                        if (r < 15) {
+                            eobrun = (1 << r) - 1;
+                            if (r) eobrun += br.bits(r);
+                            r = 64;                                // refine what is left of the band, place nothing
+                        }
+                    } else {
+                        if (sz != 1) { err = "corrupt AC refinement code"; return false; }
+                        val = br.bit() ? bit : (int16_t)-bit;
+                    }
+                    while (k <= Se) {                              // skip r zero coefficients, refining the non-zero ones passed
+                        int16_t &c = d[ZIGZAG[k++]];
+                        if (c != 0) {
+                            refine(c);
+                        } else {
+                            if (r == 0) { c = val; break; }
+                            --r;
+                        }
+                    }
+                }
+            }
+        }
+        if (restart && --todo == 0 && blk + 1 < nblocks) {
+            // byte-align, expect RSTn, reset the predictor and the end-of-band run
+            while (br.p < br.end && !(br.p[0] == 0xFF && br.p + 1 < br.end && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) ++br.p;
+            if (br.p + 2 <= br.end) br.p += 2;
+            br.reset();
+            pred = 0;
+            eobrun = 0;
+            todo = restart;
+        }
+    }
+    return true;
+}
+
 // Returns true on success.  ncomp is set as soon as the frame header is seen, so a caller can
 // report "n channels" for files that are not grayscale (the reference's check, cuh:1665).
 inline bool decode_gray(const uint8_t *data, size_t len, std::vector<uint8_t> &pix, int &w, int &h, int &ncomp,
                         std::string &err)
 {
     w = h = ncomp = 0;
+    if (len >= 8 && !memcmp(data, "\x89PNG\r\n\x1a\n", 8)) {
+        err = "PNG input: the reference's stb_image reads PNG too, this front end reads JPEG only -- convert the image to a one-component JPEG";
+        return false;
+    }
+    if (len >= 2 && data[0] == 'B' && data[1] == 'M') {
+        err = "BMP input: the reference's stb_image reads BMP too, this front end reads JPEG only -- convert the image to a one-component JPEG";
+        return false;
+    }
     if (len < 4 || data[0] != 0xFF || data[1] != 0xD8) { err = "not a JPEG file (no SOI)"; return false; }
+    bool progressive = false;
+    int scans = 0;
+    std::vector<int16_t> pcoef;                                    // progressive: 64 coefficients per block, all scans
     uint16_t quant[4][64];
     bool have_q[4] = {false, false, false, false};
     Huffman dc[4], ac[4];
     int restart = 0, qid = 0;
     size_t i = 2;
-    while (i + 4 <= len) {
+    while (i + 2 <= len) {
         if (data[i] != 0xFF) { err = "marker expected"; return false; }
         while (i < len && data[i] == 0xFF) ++i;                    // fill bytes
         if (i >= len) break;
         const int m = data[i++];
-        if (m == 0xD9) { err = "EOI before any scan"; return false; }
+        if (m == 0xD9) {
+            if (!progressive || !scans) { err = "EOI before any scan"; return false; }
+            // progressive: all scans are in -- dequantise (int16 product, like every coefficient of the sequential path) and
+            // inverse-transform every block
+            if (!have_q[qid]) { err = "frame refers to a missing quantisation table"; return false; }
+            const int bw = (w + 7) / 8, bh = (h + 7) / 8;
+            std::vector<uint8_t> padded((size_t)bw * 8 * bh * 8);
+            for (int by = 0; by < bh; ++by)
+                for (int bx = 0; bx < bw; ++bx) {
+                    int16_t *d = &pcoef[((size_t)by * bw + bx) * 64];
+                    for (int z = 0; z < 64; ++z) d[z] = (int16_t)((int)d[z] * quant[qid][z]);
+                    idct_block(d, padded.data() + ((size_t)by * 8 * bw + bx) * 8, bw * 8);
+                }
+            pix.resize((size_t)w * h);
+            for (int y = 0; y < h; ++y) memcpy(&pix[(size_t)y * w], &padded[(size_t)y * bw * 8], (size_t)w);
+            return true;
+        }
         if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;       // TEM / stray RSTn: no payload
         if (i + 2 > len) break;
         const size_t L = ((size_t)data[i] << 8) | data[i + 1];
@@ -218,8 +341,10 @@ inline bool decode_gray(const uint8_t *data, size_t len, std::vector<uint8_t> &p
         } else if (m == 0xDD) {
             if (n < 2) { err = "bad DRI"; return false; }
             restart = (seg[0] << 8) | seg[1];
-        } else if (m == 0xC0 || m == 0xC1) {                       // baseline / extended sequential
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {          // baseline / extended sequential / progressive
             if (n < 6) { err = "bad SOF"; return false; }
+            if (w) { err = "second frame header"; return false; }
+            progressive = m == 0xC2;
             if (seg[0] != 8) { err = "only 8-bit JPEG is supported"; return false; }
             h = (seg[1] << 8) | seg[2];
             w = (seg[3] << 8) | seg[4];
@@ -228,13 +353,35 @@ inline bool decode_gray(const uint8_t *data, size_t len, std::vector<uint8_t> &p
             if (ncomp != 1) { err = "not a single-channel (grayscale) JPEG"; return false; }
             if (n < 9) { err = "bad SOF"; return false; }
             qid = seg[8] & 3;
-        } else if (m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
+        } else if (m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
             if (n >= 6) ncomp = seg[5];
-            err = "progressive / lossless / arithmetic JPEG is not supported (baseline only)";
+            err = "lossless / hierarchical / arithmetic-coded JPEG is not supported (Huffman baseline, extended and progressive only)";
             return false;
         } else if (m == 0xDA) {                                    // start of scan
             if (!w) { err = "SOS before SOF"; return false; }
             if (n < 6 || seg[0] != 1) { err = "bad SOS for a one-component image"; return false; }
+            if (progressive) {
+                const int td = seg[2] >> 4, ta = seg[2] & 15, Ss = seg[3], Se = seg[4], Ah = seg[5] >> 4, Al = seg[5] & 15;
+                if (td > 3 || ta > 3 || Ss > Se || Se > 63 || Ah > 13 || Al > 13) { err = "bad progressive SOS"; return false; }
+                if (Ss == 0 && Se != 0) { err = "progressive scan mixes DC and AC coefficients"; return false; }
+                if (Ss == 0 ? (Ah == 0 && !dc[td].present) : !ac[ta].present) { err = "scan refers to a missing table"; return false; }
+                const size_t bw = (size_t)(w + 7) / 8, bh = (size_t)(h + 7) / 8;
+                if (pcoef.empty()) {
+                    // the first (DC) scan spends at least one bit per block: a header that promises more blocks than the
+                    // rest of the file can hold is damaged -- refuse before allocating
+                    if ((uint64_t)bw * bh > (uint64_t)(len - (i + L)) * 8 + 1) { err = "scan data too short for the image size"; return false; }
+                    pcoef.assign(bw * bh * 64, 0);
+                }
+                BitReader br(data + i + L, data + len);
+                if (!progressive_scan(br, pcoef.data(), bw * bh, &dc[td], &ac[ta], Ss, Se, Ah, Al, restart, err)) return false;
+                ++scans;
+                // on to the marker that ends this scan's entropy-coded data (the reader never passes one)
+                size_t pos = (size_t)(br.p - data);
+                while (pos + 1 < len && !(data[pos] == 0xFF && data[pos + 1] != 0x00 && !(data[pos + 1] >= 0xD0 && data[pos + 1] <= 0xD7))) ++pos;
+                if (pos + 1 >= len) { err = "progressive JPEG ends without EOI"; return false; }
+                i = pos;
+                continue;
+            }
             const int td = seg[2] >> 4, ta = seg[2] & 15;
             if (td > 3 || ta > 3 || !dc[td].present || !ac[ta].present || !have_q[qid]) { err = "scan refers to a missing table"; return false; }
             const int bw = (w + 7) / 8, bh = (h + 7) / 8;
@@ -283,7 +430,7 @@ inline bool decode_gray(const uint8_t *data, size_t len, std::vector<uint8_t> &p
         }
         i += L;
     }
-    err = "no scan found";
+    err = scans ? "progressive JPEG ends without EOI" : "no scan found";
     return false;
 }
 

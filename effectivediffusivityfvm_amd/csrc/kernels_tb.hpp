@@ -98,17 +98,41 @@ __device__ __forceinline__ double tb_cell(const double *lut, unsigned off, doubl
 #ifndef TB_PAIR
 #define TB_PAIR 1
 #endif
+// A/B switches of round 3 (tools/build_variant.sh):
+//   TB_FENCE 0 = scheduling fence behind every level (the default since round 1), 1 = in the MIDDLE of every level, behind
+//   the four sigma stages: the next level's lookups and lane shifts may then be hoisted over this level's tail (b - sigma,
+//   the two products, the sum) into the registers of the links that have just died, 2 = both.
+#ifndef TB_FENCE
+#define TB_FENCE 0
+#endif
+//   TB_BUF 1 = rows are addressed as buffer base (per wave tile, SGPRs) + lane offset (one VGPR) + row offset (an SGPR)
+//   instead of 64-bit pointers computed per row in VALU (10 VALU instructions per step, 12 VGPRs of addresses).
+//   TB_SPLIT 1 = the two 16-bit codes of a lane's cells travel down the levels as two registers, split once per input row,
+//   instead of one register split at every level (2 VALU instructions per level saved, T + 1 VGPRs spent).
+#ifndef TB_BUF
+#define TB_BUF 0
+#endif
+#ifndef TB_SPLIT
+#define TB_SPLIT 0
+#endif
+#if TB_BUF
+typedef unsigned int tb_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tb_rsrc(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+#endif
 // the matrix rows of a lane's two cells
 struct TbCoef {
     double c0[2], aW[2], aE[2], aS[2], aN[2], b[2];
 };
 template <bool WALL>
-__device__ __forceinline__ void tb_lookup(const double *lut, unsigned codes, TbCoef &k)
+__device__ __forceinline__ void tb_lookup(const double *lut, unsigned o0, unsigned o1, TbCoef &k)
 {
     constexpr int PS = LUT_PLANE_STRIDE * 8;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const char *base = reinterpret_cast<const char *>(lut) + (h ? (codes >> 16) : (codes & 0xFFFFu));
+        const char *base = reinterpret_cast<const char *>(lut) + (h ? o1 : o0);
         k.aW[h] = *reinterpret_cast<const double *>(base + PS);
         k.aE[h] = *reinterpret_cast<const double *>(base + 2 * PS);
         k.aS[h] = *reinterpret_cast<const double *>(base + 3 * PS);
@@ -125,6 +149,9 @@ __device__ __forceinline__ double2 tb_apply(const TbCoef &k, double2 vC, double 
     s0 = mul_add<FMA>(k.aE[0], vC.y, s0); s1 = mul_add<FMA>(k.aE[1], xe1, s1);
     s0 = mul_add<FMA>(k.aS[0], vS.x, s0); s1 = mul_add<FMA>(k.aS[1], vS.y, s1);
     s0 = mul_add<FMA>(k.aN[0], vN.x, s0); s1 = mul_add<FMA>(k.aN[1], vN.y, s1);
+#if TB_FENCE >= 1
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     s0 = k.b[0] - s0; s1 = k.b[1] - s1;
     double2 o;
     if constexpr (FMA) {
@@ -148,7 +175,7 @@ __device__ __forceinline__ double2 tb_pair(const double *lut, unsigned o0, unsig
         return o;
     } else {
         TbCoef k;
-        tb_lookup<WALL>(lut, o0 | (o1 << 16), k);
+        tb_lookup<WALL>(lut, o0, o1, k);
         return tb_apply<FMA>(k, vC, xw0, xe1, vS, vN, omw);
     }
 }
@@ -231,17 +258,44 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
 
     double2 w[T][3];                               // w[t]: 3 newest rows of sweep t
     unsigned cw[T + 1];                            // cw[t]: the two 16-bit codes of row rr-t
+#if TB_SPLIT
+    unsigned cw1[T + 1];                           // ... split: cw = first cell's code, cw1 = second cell's
+#endif
 #pragma unroll
     for (int t = 0; t < T; ++t) { w[t][0] = zero; w[t][1] = zero; w[t][2] = zero; }
 #pragma unroll
-    for (int t = 0; t <= T; ++t) cw[t] = 0u;
+    for (int t = 0; t <= T; ++t) {
+        cw[t] = 0u;
+#if TB_SPLIT
+        cw1[t] = 0u;
+#endif
+    }
 
     // prefetch the first group of three rows
     double2 nx_x[3];
     unsigned nx_c[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int rr = r_begin + k;
+#if TB_BUF
+    // the wave tile's window of the arrays as buffers: base = first input row (clamped into the array), offsets of the rows
+    // it touches stay far below 2^32 whatever the size of the context
+    const int rbase = max(r_begin, 0);
+    const unsigned span = (unsigned)(r_end + 3 - rbase) * (unsigned)nx;       // cells from rbase on that may be addressed
+    const __amdgpu_buffer_rsrc_t bx = tb_rsrc(x + (size_t)rbase * nx, span * 8u);
+    const __amdgpu_buffer_rsrc_t bc = tb_rsrc(code + (size_t)rbase * nx, span * 2u);
+    const __amdgpu_buffer_rsrc_t bo = tb_rsrc(xnew + (size_t)rbase * nx, span * 8u);
+    const unsigned vcol = (unsigned)(in_x ? col : 0);
+    auto fetch = [&](const int rr, double2 &vx_out, unsigned &vc_out) __attribute__((always_inline)) {
+        const bool rok = rr >= row_lo && rr < row_hi && rr < r_end;          // wave-uniform
+        const unsigned ro = (unsigned)((rok ? rr : rbase) - rbase) * (unsigned)nx;
+        const tb_u4 v = __builtin_amdgcn_raw_buffer_load_b128(bx, (int)(vcol * 8u), (int)(ro * 8u), 0);
+        const unsigned vc = __builtin_amdgcn_raw_buffer_load_b32(bc, (int)(vcol * 2u), (int)(ro * 2u), 0);
+        double2 vx;
+        __builtin_memcpy(&vx, &v, 16);
+        const bool ok = in_x && rok;
+        vx_out = ok ? vx : zero;
+        vc_out = ok ? vc : 0u;
+    };
+#else
+    auto fetch = [&](const int rr, double2 &vx_out, unsigned &vc_out) __attribute__((always_inline)) {
         const bool ok = in_x && rr >= row_lo && rr < row_hi && rr < r_end;
         const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col : 0);
         // the loads are issued UNCONDITIONALLY (the address is clamped into the array) and the value is
@@ -250,9 +304,12 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
         // i.e. no prefetch at all (found by removing the loads / the store: +23 % / +30 %)
         const double2 vx = ld2(x + p);
         const unsigned vc = *reinterpret_cast<const uint32_t *>(code + p);
-        nx_x[k] = ok ? vx : zero;
-        nx_c[k] = ok ? vc : 0u;                                              // rows / lanes outside the mesh: zero row
-    }
+        vx_out = ok ? vx : zero;
+        vc_out = ok ? vc : 0u;                                               // rows / lanes outside the mesh: zero row
+    };
+#endif
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fetch(r_begin + k, nx_x[k], nx_c[k]);
 
     // (Measured with the tile time stamps, tools/tb_stamps.py: waves sharing a SIMD are served
     // oldest-first, so identical tiles finish between 82 and 128 us inside one T = 8 launch.  A
@@ -275,23 +332,22 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
         for (int k = 0; k < 3; ++k) { cur_x[k] = nx_x[k]; cur_c[k] = nx_c[k]; }
         // issue the next group's loads before working on this one
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int rr = r + 3 + k;
-            const bool ok = in_x && rr >= row_lo && rr < row_hi && rr < r_end;
-            const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col : 0);
-            const double2 vx = ld2(x + p);                                   // unconditional, see above
-            const unsigned vc = *reinterpret_cast<const uint32_t *>(code + p);
-            nx_x[k] = ok ? vx : zero;
-            nx_c[k] = ok ? vc : 0u;                                          // rows / lanes outside the mesh: zero row
-        }
+        for (int k = 0; k < 3; ++k) fetch(r + 3 + k, nx_x[k], nx_c[k]);      // unconditional loads, see above
 #pragma unroll
         for (int ph = 0; ph < 3; ++ph) {
             const int rr = r + ph;                 // input row of this step
             // after this step's level-(t-1) write: newest = slot ph, previous = (ph+2)%3, oldest = (ph+1)%3
             const int sN = (ph + 1) % 3, sC = (ph + 2) % 3, sS = ph;
+#if TB_SPLIT
+#pragma unroll
+            for (int t = T; t >= 1; --t) { cw[t] = cw[t - 1]; cw1[t] = cw1[t - 1]; }
+            cw[0] = cur_c[ph] & 0xFFFFu;
+            cw1[0] = cur_c[ph] >> 16;
+#else
 #pragma unroll
             for (int t = T; t >= 1; --t) cw[t] = cw[t - 1];
             cw[0] = cur_c[ph];
+#endif
             w[0][sS] = cur_x[ph];
 #pragma unroll
             for (int t = 1; t <= T; ++t) {
@@ -305,7 +361,11 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
                 const double2 vN = w[t - 1][sN], vC = w[t - 1][sC], vS = w[t - 1][sS];
                 const double xw0 = from_lane_below(vC.y);
                 const double xe1 = from_lane_above(vC.x);
+#if TB_SPLIT
+                const unsigned o0 = cw[t], o1 = cw1[t];
+#else
                 const unsigned o0 = cw[t] & 0xFFFFu, o1 = cw[t] >> 16;
+#endif
                 const double2 o = tb_pair<GUARD, WALL, FMA>(lut, o0, o1, vC, xw0, xe1, vS, vN, omw);
                 if (t == T && ph == TB_TOUCH_PH) {
                     // CDNA counts loads and stores in one vmcnt and lets stores complete out of order, so
@@ -320,12 +380,20 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
                 if (t < T) {
                     w[t][sS] = o;
                 } else if (st_x && rt >= ry0 && rt < ry1) {
+#if TB_BUF
+                    tb_u4 ov;
+                    __builtin_memcpy(&ov, &o, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, bo, (int)(vcol * 8u), (int)((unsigned)(rt - rbase) * (unsigned)nx * 8u), 0);
+#else
                     st2(xnew + (size_t)rt * nx + col, o);
+#endif
                 }
                 // keep the scheduler from pulling the next sweeps' table lookups up here: left
                 // alone it hoists them all (180-250 VGPRs, 1-2 waves per SIMD); with the fence a
                 // step keeps ~120 VGPRs and 4 waves per SIMD hide the LDS latency instead
+#if TB_FENCE != 1
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         }
     };

@@ -129,6 +129,69 @@ def test_jpeg_decoder_byte_equal_to_stb_image_on_random_files(built, tmp_path):
     assert checked == 60
 
 
+def test_progressive_jpeg_byte_equal_to_stb_image(built, tmp_path):
+    """stbi_load also reads progressive JPEG (SOF2: spectral selection + successive approximation, stb_image.h:2194-2340,
+    3006-3025), so the front end does: 48 one-component progressive files -- the same four kinds of content, sizes with
+    partial blocks down to 1 x 1, qualities 30..100, libjpeg's default scan script (DC first + refinement, AC bands with
+    first and refinement passes, end-of-band runs), optimised tables, with and without restart markers -- must decode to
+    exactly the bytes of oracle/_ref/stb_dump (the reference's own header)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "stb_dump")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("oracle/_ref/stb_dump not built (needs /root/reference at build time)")
+    import effectivediffusivityfvm_amd as pkg
+    from PIL import Image
+    rng = np.random.default_rng(3008)
+    for k in range(48):
+        W, H = (1, 1) if k == 0 else (int(rng.integers(1, 260)), int(rng.integers(1, 260)))
+        kind = k % 4
+        if kind == 0:
+            a = np.where(rng.random((H, W)) < 0.5, 0, 255)
+        elif kind == 1:
+            f = np.kron(rng.random((H // 8 + 1, W // 8 + 1)), np.ones((8, 8)))[:H, :W]
+            a = np.where(f < 0.3, 0, np.where(f < 0.6, 150, 255))
+        elif kind == 2:
+            yy, xx = np.mgrid[0:H, 0:W]
+            a = 127.5 + 127.5 * np.sin(xx / 7.0) * np.cos(yy / 11.0)
+        else:
+            a = rng.random((H, W)) * 255
+        path = tmp_path / f"p{k}.jpg"
+        opts = dict(quality=int(rng.integers(30, 101)), progressive=True)
+        if k % 5 == 0:
+            opts["restart_marker_blocks"] = 3
+        if k % 3 == 0:
+            opts["optimize"] = True
+        Image.fromarray(a.astype(np.uint8)).save(path, **opts)
+        assert b"\xff\xc2" in open(path, "rb").read()             # really a progressive frame
+        raw = tmp_path / "out.raw"
+        r = subprocess.run([exe, str(path), str(raw)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        w, h, n = map(int, r.stdout.split())
+        want = np.fromfile(raw, dtype=np.uint8).reshape(h, w)
+        mine = pkg.load_jpeg_gray(path)
+        assert n == 1 and mine.shape == (H, W) == (h, w)
+        assert np.array_equal(mine, want), (k, W, H, opts, int((mine != want).sum()))
+    # the reference's own image re-encoded progressively (three grey levels, 2 M pixels)
+    big = tmp_path / "big.jpg"
+    Image.open(os.path.join(GOLDEN, "00042.jpg")).save(big, quality=92, progressive=True)
+    raw = tmp_path / "big.raw"
+    r = subprocess.run([exe, str(big), str(raw)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    w, h, n = map(int, r.stdout.split())
+    assert np.array_equal(pkg.load_jpeg_gray(big), np.fromfile(raw, dtype=np.uint8).reshape(h, w))
+
+
+def test_png_and_bmp_get_a_message(built, tmp_path):
+    """stbi_load reads 1-channel PNG and BMP too (stb_image.h:1094-1097); this front end reads JPEG only and says so."""
+    import effectivediffusivityfvm_amd as pkg
+    from PIL import Image
+    img = Image.fromarray(np.zeros((8, 8), dtype=np.uint8))
+    for ext, word in (("png", "PNG input"), ("bmp", "BMP input")):
+        path = tmp_path / f"x.{ext}"
+        img.save(path)
+        with pytest.raises(pkg.DeffError, match=word):
+            pkg.load_jpeg_gray(path)
+
+
 def test_jpeg_decoder_rejects_what_the_reference_rejects(built, tmp_path):
     import effectivediffusivityfvm_amd as pkg
     from PIL import Image
