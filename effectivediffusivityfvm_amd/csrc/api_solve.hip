@@ -148,12 +148,12 @@ static int wgl_resident_blocks(const deff_ctx *c, int R, bool fma, bool guard, i
 // link-symmetric 12-wave tiles (kernels_wgtile.hpp, k_sweep_wgsym): T = 8, R in WGS_ROWS
 #define WGS_DISPATCH(R_, F_, CALL)                                                              \
     do {                                                                                       \
-        if ((R_) == 3) { if (F_) { CALL(8, 3, true); } else { CALL(8, 3, false); } }            \
-        else if ((R_) == 4) { if (F_) { CALL(8, 4, true); } else { CALL(8, 4, false); } }       \
+        if ((R_) == 4) { if (F_) { CALL(8, 4, true); } else { CALL(8, 4, false); } }            \
         else { if (F_) { CALL(8, 5, true); } else { CALL(8, 5, false); } }                      \
     } while (0)
-// (R = 6 -- 72-row tiles, images up to ~1230^2 -- needs 168 VGPRs + ~100 B of scratch inside the sweep loop: not instantiated)
-static const int WGS_ROWS[] = {3, 4, 5};
+// (R = 6 -- 72-row tiles, images up to ~1230^2 -- needs 168 VGPRs + ~100 B of scratch inside the sweep loop: not instantiated;
+// R = 3 -- 36-row tiles -- is no faster than 8 waves x 4 rows, see plan_blocked_pass)
+static const int WGS_ROWS[] = {4, 5};
 static bool wgs_has_R(int R) { for (int r : WGS_ROWS) if (r == R) return true; return false; }
 
 template <int T, int R, bool F>
@@ -702,11 +702,25 @@ static int plan_blocked_pass(deff_ctx *c, SweepPlan *pl)
         // images that are ONE tall tile each (a stack of 128^2 images) recompute nothing and wait for nobody: nothing beats that
         const bool tall_whole = tall_R && pl->ntx == 1 && wgl_row_tiles(own_h, tall_R, T) == 1;
         if (!tall_whole) TRY(choose_sym_R(c, pl, T, own_h, &sym_R));
+        bool planned = false;
         if (tall_whole && c->tb_NW != WGT_WAVES) {
             TRY(plan_tall(c, pl, T, own_h, tall_R));
+            planned = true;
         } else if (sym_R) {
-            TRY(plan_sym(c, pl, T, own_h, sym_R));
-        } else {
+            // Both coefficient-resident forms may fit the chip: a sweep costs a SIMD its share of the tile's rows times the
+            // clocks a row takes at that occupancy -- measured (tools/wgr_stamps.py) ~160 at two waves per SIMD, ~142 at
+            // three.  512^2 / 640^2 stay on 8 waves x 4 rows (303-476 G against 310-481 G on 12 x 3, which is therefore
+            // not instantiated), 768^2 ... 1100^2 go to 12 waves (559 against 511 G, 746 against 688 G, 850 against 808 G).
+            bool take_sym = true;
+            if (c->tb_NW != WGS_WAVES) {
+                SweepPlan alt = *pl;
+                TRY(plan_tiles8(c, &alt, T, own_h));
+                if (alt.resident && 2 * alt.R * 160 <= 3 * sym_R * 142) { *pl = alt; take_sym = false; }
+            }
+            if (take_sym) TRY(plan_sym(c, pl, T, own_h, sym_R));
+            planned = true;
+        }
+        if (!planned) {
             TRY(plan_tiles8(c, pl, T, own_h));
             if (tall_R && (!pl->resident || c->tb_NW == WGL_WAVES)) TRY(plan_tall(c, pl, T, own_h, tall_R));
         }

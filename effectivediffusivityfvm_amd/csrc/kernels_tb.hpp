@@ -115,6 +115,12 @@ __device__ __forceinline__ double tb_cell(const double *lut, unsigned off, doubl
 #ifndef TB_SPLIT
 #define TB_SPLIT 0
 #endif
+//   TB_FAKE 1 = TIMING ONLY, results are garbage: rows come from and go to LDS instead of HBM (one ds_read_b128 / ds_write_b128
+//   per lane and row, codes made up per row), i.e. the level pipeline of a wave with no global memory at all -- what one half
+//   of a temporally split pair of waves (levels 1..T/2 | T/2+1..T, rows handed over through an LDS ring) could do at best.
+#ifndef TB_FAKE
+#define TB_FAKE 0
+#endif
 #if TB_BUF
 typedef unsigned int tb_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tb_rsrc(const void *p, unsigned bytes)
@@ -274,7 +280,13 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
     // prefetch the first group of three rows
     double2 nx_x[3];
     unsigned nx_c[3];
-#if TB_BUF
+#if TB_FAKE
+    __shared__ double2 fake_io[2][256];
+    auto fetch = [&](const int rr, double2 &vx_out, unsigned &vc_out) __attribute__((always_inline)) {
+        vx_out = fake_io[0][(threadIdx.x + rr) & 255];
+        vc_out = (unsigned)((((lane + rr) & 31) * 8 + 8) * 0x10001);
+    };
+#elif TB_BUF
     // the wave tile's window of the arrays as buffers: base = first input row (clamped into the array), offsets of the rows
     // it touches stay far below 2^32 whatever the size of the context
     const int rbase = max(r_begin, 0);
@@ -380,7 +392,9 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
                 if (t < T) {
                     w[t][sS] = o;
                 } else if (st_x && rt >= ry0 && rt < ry1) {
-#if TB_BUF
+#if TB_FAKE
+                    fake_io[1][threadIdx.x] = o;
+#elif TB_BUF
                     tb_u4 ov;
                     __builtin_memcpy(&ov, &o, 16);
                     __builtin_amdgcn_raw_buffer_store_b128(ov, bo, (int)(vcol * 8u), (int)((unsigned)(rt - rbase) * (unsigned)nx * 8u), 0);

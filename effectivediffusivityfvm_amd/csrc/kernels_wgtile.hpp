@@ -684,6 +684,13 @@ __device__ __forceinline__ void wgs_sweeps(double2 (&xr)[R], const WgsCoef<R> &k
 // cleanly -- the library's own objects were not involved, the cooperative path bypasses the event chain -- and with the
 // fallback above the plain launch needs no such guarantee.)
 // Same arithmetic, same tiles, same results bit for bit as npass launches of k_sweep_wgtile.
+// (Round 3, measured and dropped -- profiles/r03_resident_tile_stamps.log: the exchange costs ~2.9 of a 1024^2 pass's 9.9 us
+// as a chain of three device-coherent round trips -- rim stores acknowledged 1.1-1.9, flag seen 1.0, halo read 0.6.  A tagged
+// mailbox -- every cell as one 16-byte element {value, pass tag}, no flag, no acknowledgement, readers fetch until all tags
+// are fresh -- polls with every wave instead of eight lanes and was SLOWER (wait 4.4-6.8 us, growing with the rows per wave);
+// with all loads of a poll in flight together one 150 001-sweep solve came out WRONG on a quiet GPU while the short parity
+// tests passed: whether a 16-byte sc1 access is single-copy atomic against another XCD is nothing this library can
+// establish, so nothing here rests on it.  Flags after acknowledged stores stay.)
 constexpr unsigned long long WGR_TIMEOUT = 200000000ull;       // 2 s
 constexpr int WGR_FLAG_STRIDE = 64;                            // unsigneds between two tiles' flags: one 256-byte block each, so that
                                                                // ~2 000 polling lanes do not queue on a handful of cache lines

@@ -684,7 +684,7 @@ def test_tall_tiles_whole_images_beyond_one_per_cu(pkg, oracle):
 SYM_SHAPES = [(300, 200), (1030, 137), (600, 500), (250, 333), (2, 64), (97, 241), (122, 9), (1001, 333)]
 
 
-@pytest.mark.parametrize("R", [3, 4, 5])
+@pytest.mark.parametrize("R", [4, 5])
 @pytest.mark.parametrize("shape", SYM_SHAPES)
 def test_sym_tiles_vs_oracle(pkg, oracle, shape, R):
     """k_sweep_wgsym<8, R>: ragged strips and row tiles, odd widths (padded column, b looked at everywhere), images shorter
@@ -716,7 +716,7 @@ def test_sym_tiles_vs_oracle(pkg, oracle, shape, R):
         assert_field(s.get_field(), want2)
 
 
-@pytest.mark.parametrize("R", [3, 5])
+@pytest.mark.parametrize("R", [4, 5])
 def test_sym_tiles_omega_one_boundary_values_and_fma(pkg, oracle, R):
     nx, ny = 300, 250
     rng = np.random.default_rng(R + 40)
@@ -743,7 +743,7 @@ def test_sym_tiles_are_taken_only_for_verified_symmetric_unguarded_systems(pkg, 
     non-zero test: the native assembly and the same matrix through the seam take it; a matrix with scaled E (or N) links,
     a zero-diffusivity phase (guard) and tb_sym = 2 do not -- and every case gives its own oracle's bits."""
     rng = np.random.default_rng(2718)
-    nx, ny = 300, 260
+    nx, ny = 700, 600                                     # 7 strips x 19 row tiles: the 12-wave form is the planner's own choice
     pix = rand_mask(rng, nx, ny, 0.5)
     D = oracle.fill_D_2phase(pix, 1.0, 1e-2)
     A, b = oracle.discretize(D, 0.0, 1.0)
@@ -812,6 +812,7 @@ def test_sym_tiles_stack_with_frozen_images_and_stream(pkg, oracle):
         A, b = oracle.discretize(D, 0.0, 1.0)
         want.append(oracle.jacobi(A, b, oracle.linear_guess(nx, ny, 0.0, 1.0), D, 0.0, 1.0, 1e-3, 6000, check_every=200))
     with pkg.Solver(nx, ny, nimg=B, kernel="matfree_tb") as s:
+        s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 12)
         s.set_image(np.stack(pixs[:B]))
         s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
         s.init_linear(0.0, 1.0)
@@ -825,6 +826,7 @@ def test_sym_tiles_stack_with_frozen_images_and_stream(pkg, oracle):
         assert_field(got[k * ny:(k + 1) * ny], x)
     assert len({w[0] for w in want[:B]}) > 1
     with pkg.Solver(nx, ny, nimg=3, kernel="matfree_tb") as s:
+        s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 12)
         out = s.solve_stream(pixs, 1e-2, 1.0, 0.0, 1.0, 1e-3, 6000, check_every=200, want_fields=True)
         assert s.plan()["tb_NW"] == 12
     for k in range(7):

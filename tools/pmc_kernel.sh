@@ -7,7 +7,7 @@ out=$root/gpurun_out/pmc_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --pmc $ctrs --output-format csv -d "$out" -- python3 "$root/bench.py" --steps 1 --warmup 0 --sweeps-per-step 24 --no-cpu-baseline --no-small-image --no-live-traffic --explicit-sweeps 0 "$@" > "$out/bench.log" 2>&1 || { echo "pmc run failed"; tail -5 "$out/bench.log"; exit 1; }
+rocprofv3 --pmc $ctrs --output-format csv -d "$out" -- python3 "$root/bench.py" --steps 1 --warmup 0 --sweeps-per-step 24 --no-cpu-baseline --no-small-image --no-live-traffic --no-live-stats --no-iters-to-tol --explicit-sweeps 0 "$@" > "$out/bench.log" 2>&1 || { echo "pmc run failed"; tail -5 "$out/bench.log"; exit 1; }
 python3 - "$out" <<'PY'
 import csv,glob,sys,collections
 f=max(glob.glob(sys.argv[1]+"/*/*_counter_collection.csv"))
