@@ -244,7 +244,7 @@ try {
     else if (!strcmp(key, "serpentine")) c->serpentine = value ? 1 : 0;
     else if (!strcmp(key, "tb_T")) c->tb_T = value;
     else if (!strcmp(key, "tb_LY")) c->tb_LY = value;
-    else if (!strcmp(key, "tb_impl")) c->tb_impl = value > 2 ? 0 : value;
+    else if (!strcmp(key, "tb_impl")) c->tb_impl = value > 3 ? 0 : value;
     else if (!strcmp(key, "tb_R")) c->tb_R = value;
     else if (!strcmp(key, "tb_debug_stall")) c->tb_debug_stall = value;
     else if (!strcmp(key, "tb_sym")) c->tb_sym = value;

@@ -521,4 +521,221 @@ __global__ __launch_bounds__(256, (T >= 6 ? 3 : 1)) void k_sweep_matfree_tb(cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Temporal split across a PAIR of waves (round 3; tuning tb_impl = 3, T = 8 only): wave A streams the
+// rows of a tile from HBM through levels 1..T/2 and hands every level-T/2 row (with the row's codes) to wave B through a
+// ring in LDS; wave B runs levels T/2+1..T and stores.  Each wave holds half the windows (~120 VGPRs: four waves per SIMD),
+// A's vmcnt counts loads only and B never waits for memory at all; a SIMD carries two tiles (two pairs) instead of three,
+// so the chunks are taller and recompute less.  No barrier: the ring is a single-producer / single-consumer queue with two
+// counters (rows produced / rows consumed), LDS operations of one wave execute in order, and both waves run the same
+// number of steps over the same tiles, so every wait is for a row the partner is certain to produce / consume.
+// Same arithmetic per cell as tb_strip -- the levels are just dealt to two waves -- so the same bits.
+#ifndef TB2_MINW
+#define TB2_MINW 4
+#endif
+constexpr int TB2_RING = 8;                                    // level-T/2 rows in flight between the two waves of a pair
+struct Tb2Shared {
+    double2 x[4][TB2_RING][64];
+    unsigned c[4][TB2_RING][64];
+    int prod[4], cons[4];
+};
+
+// ROLE 1 = wave A (levels 1..T/2, reads HBM, writes the ring), 2 = wave B (reads the ring, levels T/2+1..T, writes HBM).
+template <int T, bool GUARD, bool WALL, bool FMA, int ROLE>
+__device__ __forceinline__ void tb_strip_half(const double *lut, const uint16_t *__restrict__ code,
+                                              const double *__restrict__ x, double *__restrict__ xnew, int nx,
+                                              int ny, int row_lo, int own_hi, int tx, int ntx, int shift, int ry0, int LY,
+                                              int lane, double omw, double2 (*ring_x)[64], unsigned (*ring_c)[64],
+                                              int *prod, int *cons, int &k, int &seen)
+{
+    static_assert(T % 2 == 0 && T >= 2, "the split needs an even T");
+    constexpr int H = T / 2;
+    constexpr int HW = (T + 1) & ~1;
+    constexpr int WOUT = TB_COLS - 2 * HW;
+    constexpr int TLO = ROLE == 1 ? 1 : H + 1, THI = ROLE == 1 ? H : T;
+    const int col = tx * WOUT - shift + 2 * lane;
+    const bool in_x = col >= 0 && col < nx;
+    const int out_lo = (tx == 0) ? 0 : tx * WOUT - shift + HW;
+    const int out_hi = (tx == ntx - 1) ? nx : tx * WOUT - shift + TB_COLS - HW;
+    const int row_hi = row_lo + ny;
+    const int ry1 = min(ry0 + LY, own_hi);
+    const int r_begin = max(ry0 - T, row_lo), r_end = ry1 + T;
+    const bool st_x = in_x && (col >= out_lo) && (col < out_hi);
+    const double2 zero = make_double2(0.0, 0.0);
+
+    double2 w[T][3];                               // w[t]: 3 newest rows of sweep t (A uses 0..H-1, B uses H..T-1)
+    unsigned cw[T + 1];                            // cw[t]: the two 16-bit codes of row rr-t (A: 0..H, B: H..T)
+#pragma unroll
+    for (int t = 0; t < T; ++t) { w[t][0] = zero; w[t][1] = zero; w[t][2] = zero; }
+#pragma unroll
+    for (int t = 0; t <= T; ++t) cw[t] = 0u;
+
+    double2 nx_x[3] = {zero, zero, zero};
+    unsigned nx_c[3] = {0u, 0u, 0u};
+    auto fetch = [&](const int rr, double2 &vx_out, unsigned &vc_out) __attribute__((always_inline)) {
+        const bool ok = in_x && rr >= row_lo && rr < row_hi && rr < r_end;
+        const size_t p = (size_t)(ok ? rr : 0) * nx + (ok ? col : 0);
+        const double2 vx = ld2(x + p);                                       // unconditional, see tb_strip
+        const unsigned vc = *reinterpret_cast<const uint32_t *>(code + p);
+        vx_out = ok ? vx : zero;
+        vc_out = ok ? vc : 0u;
+    };
+    if constexpr (ROLE == 1) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fetch(r_begin + q, nx_x[q], nx_c[q]);
+    }
+    // The two waves meet once per GROUP of three steps, at its head (a wait inside the unrolled steps -- a loop in the middle of
+    // the level code -- cost wave A 66 VGPRs: 196 instead of 130): A starts a group when the ring has room for its three rows,
+    // B when its three rows are there; with 8 slots the two conditions cannot both fail.
+    auto meet = [&]() __attribute__((always_inline)) {
+        if constexpr (ROLE == 1) {
+            while (k + 3 - seen > TB2_RING) {
+                seen = *reinterpret_cast<volatile int *>(cons);
+                if (k + 3 - seen > TB2_RING) __builtin_amdgcn_s_sleep(1);
+            }
+        } else {
+            while (seen - (k + 3) < 0) {
+                seen = *reinterpret_cast<volatile int *>(prod);
+                if (seen - (k + 3) < 0) __builtin_amdgcn_s_sleep(1);
+            }
+            *reinterpret_cast<volatile int *>(cons) = k;           // the rows of the groups before this one are in registers
+        }
+    };
+    // A: hand row k to B
+    auto emit = [&](const double2 o, const unsigned c) __attribute__((always_inline)) {
+        const int slot = k & (TB2_RING - 1);
+        ring_x[slot][lane] = o;
+        ring_c[slot][lane] = c;
+        asm volatile("" ::: "memory");                 // the counter goes out behind the row (LDS executes a wave's operations in order)
+        *reinterpret_cast<volatile int *>(prod) = ++k;
+    };
+    // B: take row k
+    auto take = [&](double2 &o, unsigned &c) __attribute__((always_inline)) {
+        const int slot = k & (TB2_RING - 1);
+        o = ring_x[slot][lane];
+        c = ring_c[slot][lane];
+        ++k;
+    };
+
+    auto group = [&](const int r, auto trim_tag) __attribute__((always_inline)) {
+        constexpr bool TRIM = decltype(trim_tag)::value;
+        double2 cur_x[3];
+        unsigned cur_c[3];
+        meet();
+        if constexpr (ROLE == 1) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { cur_x[q] = nx_x[q]; cur_c[q] = nx_c[q]; }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) fetch(r + 3 + q, nx_x[q], nx_c[q]);
+        } else {
+            // the group's three rows are there (meet): read them all now, use them step by step
+#pragma unroll
+            for (int q = 0; q < 3; ++q) take(cur_x[q], cur_c[q]);
+        }
+#pragma unroll
+        for (int ph = 0; ph < 3; ++ph) {
+            const int rr = r + ph;
+            const int sN = (ph + 1) % 3, sC = (ph + 2) % 3, sS = ph;
+            if constexpr (ROLE == 1) {
+#pragma unroll
+                for (int t = H; t >= 1; --t) cw[t] = cw[t - 1];
+                cw[0] = cur_c[ph];
+                w[0][sS] = cur_x[ph];
+            } else {
+#pragma unroll
+                for (int t = T; t >= H + 1; --t) cw[t] = cw[t - 1];
+                cw[H] = cur_c[ph];
+                w[H][sS] = cur_x[ph];
+            }
+#pragma unroll
+            for (int t = TLO; t <= THI; ++t) {
+                const int rt = rr - t;
+                if constexpr (TRIM) {
+                    if (rt < row_lo || rt - t < ry0 - T) {   // wave-uniform: above the mesh / above this level's halo
+                        if (ROLE == 1 && t == H) emit(zero, 0u);               // B skips its levels of this step too; it still takes a row
+                        __builtin_amdgcn_sched_barrier(0);
+                        continue;
+                    }
+                }
+                const double2 vN = w[t - 1][sN], vC = w[t - 1][sC], vS = w[t - 1][sS];
+                const double xw0 = from_lane_below(vC.y);
+                const double xe1 = from_lane_above(vC.x);
+                const unsigned o0 = cw[t] & 0xFFFFu, o1 = cw[t] >> 16;
+                const double2 o = tb_pair<GUARD, WALL, FMA>(lut, o0, o1, vC, xw0, xe1, vS, vN, omw);
+                if (ROLE == 1 && t == H && ph == TB_TOUCH_PH) {
+                    // A's vmcnt holds loads only: ask for the prefetched group once per group, late (see tb_strip)
+                    asm volatile("" :: "v"(nx_x[0].x), "v"(nx_x[0].y), "v"(nx_x[1].x), "v"(nx_x[1].y), "v"(nx_x[2].x),
+                                 "v"(nx_x[2].y), "v"(nx_c[0]), "v"(nx_c[1]), "v"(nx_c[2]));
+                }
+                if (ROLE == 1 && t == H) {
+                    emit(o, cw[H]);
+                } else if (t < T) {
+                    w[t][sS] = o;
+                } else if (st_x && rt >= ry0 && rt < ry1) {
+                    st2(xnew + (size_t)rt * nx + col, o);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    constexpr int TRIMMED = ((2 * T + 2) / 3) * 3;
+    int r = r_begin;
+    for (; r < r_begin + TRIMMED && r < r_end; r += 3) group(r, TbTag<true>{});
+    for (; r < r_end; r += 3) group(r, TbTag<false>{});
+}
+
+// grid: persistent workgroups of 8 waves = 4 pairs; wave tiles are numbered and dealt exactly as in k_sweep_matfree_tb (4 per
+// workgroup), wave w and wave w + 4 share tile w (A = the lower one).
+template <int T, bool FMA, bool GUARD>
+__global__ __launch_bounds__(512, TB2_MINW) void k_sweep_matfree_tb2(const double *__restrict__ lut_g,
+                                                          const uint16_t *__restrict__ code,
+                                                          const double *__restrict__ x,
+                                                          double *__restrict__ xnew, int nx, int ny,
+                                                          int img_stride, int dom_lo, int own_lo,
+                                                          int own_h, int cpi,
+                                                          const uint8_t *__restrict__ active,
+                                                          int LY, int ntx, int nbt, int gy, int flip,
+                                                          int xmajor, int allb, int nrows, int shift,
+                                                          double omw, unsigned long long *__restrict__ stamps)
+{
+    __shared__ double lut[LUT_DOUBLES];
+    __shared__ Tb2Shared ring;
+    if (threadIdx.x < 4) { ring.prod[threadIdx.x] = 0; ring.cons[threadIdx.x] = 0; }
+    load_lut<512>(lut, lut_g, nrows);                              // (ends in a barrier: the counters are zero for everybody)
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#ifdef TB2_FORCE_ROLE
+    const int pair = wave & 3, role = TB2_FORCE_ROLE;
+#else
+    const int pair = wave & 3, role = wave >> 2;
+#endif
+    const unsigned total = (unsigned)nbt;
+    const unsigned wtiles = (unsigned)ntx * (unsigned)gy;
+    const unsigned per = (total + 7u) / 8u;
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned nper = gridDim.x >> 3;
+    int k = 0, seen = 0;                                           // rows handed over so far / the partner's counter as last read
+    for (unsigned kk = blockIdx.x >> 3; kk < per; kk += nper) {
+        const unsigned bt = xcd * per + (flip ? per - 1u - kk : kk);
+        if (bt >= total) continue;
+        const unsigned wt = bt * 4u + (unsigned)pair;
+        if (wt >= wtiles) continue;                    // the same for both waves of the pair
+        const int tx = xmajor ? (int)(wt % (unsigned)ntx) : (int)(wt / (unsigned)gy);
+        const int bty = xmajor ? (int)(wt / (unsigned)ntx) : (int)(wt % (unsigned)gy);
+        const int img = bty / cpi;
+        if (active && !active[img]) continue;
+        const int row_lo = dom_lo + img * img_stride;
+        const int own0 = own_lo + img * img_stride;
+        const int ry0 = own0 + (bty - img * cpi) * LY;
+        const bool wall = allb || tx == 0 || tx == ntx - 1;
+#define TB2_CALL(WALL_, ROLE_)                                                                                     \
+    tb_strip_half<T, GUARD, WALL_, FMA, ROLE_>(lut, code, x, xnew, nx, ny, row_lo, own0 + own_h, tx, ntx, shift, ry0, LY, lane, \
+                                               omw, ring.x[pair], ring.c[pair], &ring.prod[pair], &ring.cons[pair], k, seen)
+        if (role == 0) { if (wall) TB2_CALL(true, 1); else TB2_CALL(false, 1); }
+        else { if (wall) TB2_CALL(true, 2); else TB2_CALL(false, 2); }
+#undef TB2_CALL
+    }
+}
+
 }  // namespace deff

@@ -81,7 +81,8 @@ int deff_get_kernel(const deff_ctx *ctx, int *kernel_in_use);
 /* tuning knob; 0 restores the default.  Keys: "rows_explicit", "rows_matfree", "wg_matfree",
  * "nt_explicit", "serpentine", "tb_T" (sweeps per pass: 1,2,4,6,8), "tb_LY" (rows per chunk), "tb_wg",
  * "tb_xmajor", "tb_wall_halo", "dict" (harvest a row dictionary from explicit systems: 1 default),
- * "tb_impl" (1 streaming, 2 workgroup tiles), "tb_R", "tb_NW" (8 or 16 waves per tile: 16 = tall resident tiles),
+ * "tb_impl" (1 streaming, 2 workgroup tiles, 3 streaming with a pair of waves per tile), "tb_R", "tb_NW" (8 / 12 / 16 waves per
+ *   tile: 12 = link-symmetric matrix rows in registers, 16 = tall resident tiles),
  * "tb_launch" (workgroup tiles whose tiles all fit the chip
  *   run every pass between two checks in ONE launch, neighbouring tiles synchronised by flags: 1 = one launch per
  *   pass instead; a resident launch that cannot make progress -- another process holds part of the GPU -- gives up
