@@ -128,6 +128,14 @@ __device__ __forceinline__ double tb_cell(const double *lut, unsigned off, doubl
 #ifndef TB_FAKE
 #define TB_FAKE 0
 #endif
+//   TB_PIPE 1 = in the steady-state groups the LINK lookups of level t + 1 are issued in the middle of level t, right behind
+//   its four sigma stages, into the registers of level t's links (dead by then); c0 / b of level t are issued at its head and
+//   needed at its tail.  The wave then waits for a level's first coefficients once per step instead of once per level.
+//   Same registers (168 VGPRs at T = 8), bit-exact, and within the run-to-run noise of the default: 1 148-1 191 against
+//   1 145-1 157 G at T = 8, 1 130-1 141 against 1 118-1 157 at T = 6, 1 014-1 063 against 1 006-1 052 at T = 4.
+#ifndef TB_PIPE
+#define TB_PIPE 0
+#endif
 #if TB_BUF
 typedef unsigned int tb_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tb_rsrc(const void *p, unsigned bytes)
@@ -383,6 +391,67 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
             cw[0] = cur_c[ph];
 #endif
             w[0][sS] = cur_x[ph];
+#if TB_PIPE && !TB_SPLIT && !TB_FAKE && TB_BUF < 2
+            if constexpr (!TRIM && !GUARD) {
+                constexpr int PS = LUT_PLANE_STRIDE * 8;
+                TbCoef k;
+                auto links = [&](const unsigned cwt) __attribute__((always_inline)) {
+                    const char *b0 = reinterpret_cast<const char *>(lut) + (cwt & 0xFFFFu);
+                    const char *b1 = reinterpret_cast<const char *>(lut) + (cwt >> 16);
+                    k.aW[0] = *reinterpret_cast<const double *>(b0 + PS);     k.aW[1] = *reinterpret_cast<const double *>(b1 + PS);
+                    k.aE[0] = *reinterpret_cast<const double *>(b0 + 2 * PS); k.aE[1] = *reinterpret_cast<const double *>(b1 + 2 * PS);
+                    k.aS[0] = *reinterpret_cast<const double *>(b0 + 3 * PS); k.aS[1] = *reinterpret_cast<const double *>(b1 + 3 * PS);
+                    k.aN[0] = *reinterpret_cast<const double *>(b0 + 4 * PS); k.aN[1] = *reinterpret_cast<const double *>(b1 + 4 * PS);
+                };
+                links(cw[1]);
+#pragma unroll
+                for (int t = 1; t <= T; ++t) {
+                    const int rt = rr - t;
+                    const double2 vN = w[t - 1][sN], vC = w[t - 1][sC], vS = w[t - 1][sS];
+                    const double xw0 = from_lane_below(vC.y);
+                    const double xe1 = from_lane_above(vC.x);
+                    {
+                        const char *b0 = reinterpret_cast<const char *>(lut) + (cw[t] & 0xFFFFu);
+                        const char *b1 = reinterpret_cast<const char *>(lut) + (cw[t] >> 16);
+                        k.c0[0] = *reinterpret_cast<const double *>(b0); k.c0[1] = *reinterpret_cast<const double *>(b1);
+                        if constexpr (WALL) { k.b[0] = *reinterpret_cast<const double *>(b0 + 5 * PS); k.b[1] = *reinterpret_cast<const double *>(b1 + 5 * PS); }
+                        else { k.b[0] = 0.0; k.b[1] = 0.0; }
+                    }
+                    double s0 = k.aW[0] * xw0, s1 = k.aW[1] * vC.x;
+                    s0 = mul_add<FMA>(k.aE[0], vC.y, s0); s1 = mul_add<FMA>(k.aE[1], xe1, s1);
+                    s0 = mul_add<FMA>(k.aS[0], vS.x, s0); s1 = mul_add<FMA>(k.aS[1], vS.y, s1);
+                    s0 = mul_add<FMA>(k.aN[0], vN.x, s0); s1 = mul_add<FMA>(k.aN[1], vN.y, s1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t < T) links(cw[t + 1]);                               // into the registers of the links just used
+                    s0 = k.b[0] - s0; s1 = k.b[1] - s1;
+                    double2 o;
+                    if constexpr (FMA) {
+                        s0 = k.c0[0] * s0; s1 = k.c0[1] * s1;
+                        o.x = __builtin_fma(omw, vC.x, s0); o.y = __builtin_fma(omw, vC.y, s1);
+                    } else {
+                        const double m0 = omw * vC.x, m1 = omw * vC.y;
+                        s0 = k.c0[0] * s0; s1 = k.c0[1] * s1;
+                        o.x = m0 + s0; o.y = m1 + s1;
+                    }
+                    if (t == T && ph == TB_TOUCH_PH)
+                        asm volatile("" :: "v"(nx_x[0].x), "v"(nx_x[0].y), "v"(nx_x[1].x), "v"(nx_x[1].y), "v"(nx_x[2].x),
+                                     "v"(nx_x[2].y), "v"(nx_c[0]), "v"(nx_c[1]), "v"(nx_c[2]));
+                    if (t < T) {
+                        w[t][sS] = o;
+                    } else if (st_x && rt >= ry0 && rt < ry1) {
+#if TB_BUF
+                        tb_u4 ov;
+                        __builtin_memcpy(&ov, &o, 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(ov, bo, (int)(vcol * 8u), (int)((unsigned)(rt - rbase) * (unsigned)nx * 8u), 0);
+#else
+                        st2(xnew + (size_t)rt * nx + col, o);
+#endif
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                continue;                                                      // next step of the group
+            }
+#endif
 #pragma unroll
             for (int t = 1; t <= T; ++t) {
                 const int rt = rr - t;             // row produced by sweep t in this step
