@@ -439,9 +439,15 @@ def test_driver_batch_groups_images(built, tmp_path, oracle):
     _write_input(tmp_path / "input.txt", Phases=2, Ds="1e-2", Df=1, MeshAmpX=1, MeshAmpY=1, CR=1, CL=0,
                  OutputName="out.csv", printCMap=0, Convergence="1e-4", MaxIter="2e5", Verbose=0, RunBatch=1,
                  NumImages=7)
+    # image 5 is stored as a PROGRESSIVE JPEG of the same pixels' source (its own decode is what its row must match)
+    a5 = np.where(np.random.default_rng(5).random((64, 96)) < 0.6, 0, 255).astype(np.uint8)
+    Image.fromarray(a5).save(tmp_path / "00005.jpg", quality=90, progressive=True)
+    pixs[5] = pkg.load_jpeg_gray(tmp_path / "00005.jpg")
     results = {}
-    # 2: three worker threads on one GPU, writing a progress file
-    for bs, extra in ((3, []), (1, []), (2, ["--devices", "0,0,0", "--progress", "prog.txt"])):
+    # 2: three worker threads on one GPU, writing a progress file; 3 with one / 1 with three prefetch threads per worker
+    # (images then reach the solver out of index order: rows still land by index)
+    for bs, extra in ((3, ["--prefetch-threads", "1"]), (1, ["--prefetch-threads", "3"]),
+                      (2, ["--devices", "0,0,0", "--progress", "prog.txt"])):
         r = subprocess.run([EXE, "input.txt", "--json", f"res{bs}.json", "--batch-size", str(bs)] + extra,
                            cwd=tmp_path, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr + r.stdout
