@@ -913,8 +913,12 @@ static int launch_resident_passes(deff_ctx *c, const SweepPlan &pl, int64_t *n)
         c->res_redo = 0;
         c->res_omega = pl.omega;
     }
+    // a resident launch holds the whole chip until it ends: keep one to ~25 ms (a pass of T sweeps takes about n * T / 0.9e12 s
+    // on these forms), between 64 and 4 096 passes -- the reference's 10 000-sweep interval is one launch up to ~1500^2
+    const double pass_s = (double)c->n * pl.T / 0.9e12;
+    const int64_t cap = std::max<int64_t>(64, std::min<int64_t>(4096, (int64_t)(25e-3 / pass_s)));
     while (np > 0) {
-        const int chunk = (int)(np < 4096 ? np : 4096);
+        const int chunk = (int)(np < cap ? np : cap);
         if (c->res_epoch > (1u << 30)) {
             // the flags count passes since they were last cleared and are compared through a signed difference: start a
             // new count long before it could wrap (stream-ordered: every earlier launch has finished with them)
