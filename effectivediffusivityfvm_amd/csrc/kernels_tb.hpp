@@ -168,9 +168,26 @@ __device__ __forceinline__ double2 tb_apply(const TbCoef &k, double2 vC, double 
 {
     double s0 = k.aW[0] * xw0, s1 = k.aW[1] * vC.x;
     s0 = mul_add<FMA>(k.aE[0], vC.y, s0); s1 = mul_add<FMA>(k.aE[1], xe1, s1);
+#if TB_FENCE == 3
+    // TB_FENCE 3 (default arithmetic only): everything above needs rows of EARLIER steps only, and so does the product of the
+    // N term; the row this step's previous level has just produced (vS) enters below.  With the fence here the head of level
+    // t + 1 -- lookups, lane shifts, two of its four terms and the N product -- may overlap the tail of level t.  The order of
+    // the additions is the reference's (W, E, S, N): same bits.
+    if constexpr (!FMA) {
+        const double pn0 = k.aN[0] * vN.x, pn1 = k.aN[1] * vN.y;
+        __builtin_amdgcn_sched_barrier(0);
+        s0 = s0 + k.aS[0] * vS.x; s1 = s1 + k.aS[1] * vS.y;
+        s0 = s0 + pn0; s1 = s1 + pn1;
+    } else {
+        __builtin_amdgcn_sched_barrier(0);
+        s0 = mul_add<FMA>(k.aS[0], vS.x, s0); s1 = mul_add<FMA>(k.aS[1], vS.y, s1);
+        s0 = mul_add<FMA>(k.aN[0], vN.x, s0); s1 = mul_add<FMA>(k.aN[1], vN.y, s1);
+    }
+#else
     s0 = mul_add<FMA>(k.aS[0], vS.x, s0); s1 = mul_add<FMA>(k.aS[1], vS.y, s1);
     s0 = mul_add<FMA>(k.aN[0], vN.x, s0); s1 = mul_add<FMA>(k.aN[1], vN.y, s1);
-#if TB_FENCE >= 1
+#endif
+#if TB_FENCE == 1 || TB_FENCE == 2
     __builtin_amdgcn_sched_barrier(0);
 #endif
     s0 = k.b[0] - s0; s1 = k.b[1] - s1;
@@ -507,7 +524,7 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
                 // keep the scheduler from pulling the next sweeps' table lookups up here: left
                 // alone it hoists them all (180-250 VGPRs, 1-2 waves per SIMD); with the fence a
                 // step keeps ~120 VGPRs and 4 waves per SIMD hide the LDS latency instead
-#if TB_FENCE != 1
+#if TB_FENCE != 1 && TB_FENCE != 3
                 __builtin_amdgcn_sched_barrier(0);
 #endif
             }
