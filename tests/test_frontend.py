@@ -256,6 +256,15 @@ def test_front_end_survives_damaged_input_under_sanitizers(tmp_path):
     r = subprocess.run([exe, img, "4000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "accepted" in r.stdout and "rejected" in r.stdout
+    # the same with a PROGRESSIVE seed (several scans, refinement passes, end-of-band runs, restart markers): the multi-scan
+    # path of the decoder under the same damage
+    from PIL import Image
+    prog = str(tmp_path / "good_progressive.jpg")
+    Image.open(img).save(prog, quality=85, progressive=True, restart_marker_blocks=5)
+    assert b"\xff\xc2" in open(prog, "rb").read()
+    r = subprocess.run([exe, prog, "4000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "accepted" in r.stdout and "rejected" in r.stdout
 
 
 @pytest.mark.gpu
