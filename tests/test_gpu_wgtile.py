@@ -833,3 +833,40 @@ def test_sym_tiles_stack_with_frozen_images_and_stream(pkg, oracle):
         it, deff, conv, x, _, _ = want[k]
         assert (out[k].iters, out[k].deff_raw, out[k].conv) == (it, deff, conv)
         assert_field(out[k].field, x)
+
+
+def test_resident_fallback_in_stacks_and_streams(pkg, oracle):
+    """The redo of an aborted resident interval with frozen images and with refilled slots around it: a stack whose images stop
+    at different checks and a stream through 3 slots, both with a tile that never publishes from the first resident launch on
+    (tb_debug_stall) -- the first interval is redone with one launch per pass, the rest of the solve runs that way, and every
+    image has the oracle's sweeps, Deff, conv and field."""
+    nx, ny, B = 250, 90, 4
+    rng = np.random.default_rng(321)
+    pixs = [rand_mask(rng, nx, ny, 0.35 + 0.1 * k) for k in range(7)]
+    want = []
+    for k in range(7):
+        D = oracle.fill_D_2phase(pixs[k], 1.0, 1e-2)
+        A, b = oracle.discretize(D, 0.0, 1.0)
+        want.append(oracle.jacobi(A, b, oracle.linear_guess(nx, ny, 0.0, 1.0), D, 0.0, 1.0, 1e-3, 6000, check_every=200))
+    with pkg.Solver(nx, ny, nimg=B, kernel="matfree_tb") as s:
+        s.set_tuning("tb_impl", 2)
+        s.set_tuning("tb_debug_stall", 3)
+        s.set_image(np.stack(pixs[:B]))
+        s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        res = s.solve(1e-3, 6000, check_every=200)
+        got = s.get_field()
+        assert s.plan_value("tb_fallbacks") == 1 and s.plan()["tb_resident"] == 0
+    for k in range(B):
+        it, deff, conv, x, _, _ = want[k]
+        assert (res[k].iters, res[k].deff_raw, res[k].conv) == (it, deff, conv)
+        assert_field(got[k * ny:(k + 1) * ny], x)
+    with pkg.Solver(nx, ny, nimg=3, kernel="matfree_tb") as s:
+        s.set_tuning("tb_impl", 2)
+        s.set_tuning("tb_debug_stall", 2)
+        out = s.solve_stream(pixs, 1e-2, 1.0, 0.0, 1.0, 1e-3, 6000, check_every=200, want_fields=True)
+        assert s.plan_value("tb_fallbacks") == 1
+    for k in range(7):
+        it, deff, conv, x, _, _ = want[k]
+        assert (out[k].iters, out[k].deff_raw, out[k].conv) == (it, deff, conv)
+        assert_field(out[k].field, x)
