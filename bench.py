@@ -45,6 +45,16 @@ FP64_INSTR_PEAK_T = 39.3216
 FP64_INSTR_PER_CELL = {False: 11, True: 7}   # tb_cell(): default arithmetic / contracted (kernels_tb.hpp)
 
 
+def child_env():
+    """Environment of the rocprofv3 child runs: this process's, minus what a torch.distributed launcher put there (a child
+    must not join the parent's process group or bind its rendezvous port)."""
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+            "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")
+    env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith("TORCHELASTIC_") and not k.startswith("TORCH_NCCL_")}
+    env["TMPDIR"] = "/tmp"
+    return env
+
+
 def live_traffic(n, kernel, kernel_used):
     """HBM bytes per launch of the dominant sweep kernel, measured NOW: two child runs of this script under
     `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE; separate passes, the program itself after `--`), corrected as
@@ -63,7 +73,7 @@ def live_traffic(n, kernel, kernel_used):
     if want is None:
         return None
     got = {}
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = child_env()
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
             cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.abspath(__file__),
@@ -99,7 +109,7 @@ def live_kernel_stats(n, kernel, kernel_used, steps, warmup, sweeps_per_step, om
             "scalar": "k_sweep_scalar"}.get(kernel_used)
     if not os.path.exists(exe) or want is None:
         return None
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = child_env()
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
         cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "--", sys.executable,
                os.path.abspath(__file__), "--size", str(n), "--kernel", kernel, "--steps", str(steps), "--warmup", str(warmup),
