@@ -170,7 +170,8 @@ static int wgl_resident_blocks(const deff_ctx *c, int R, bool fma, bool guard, i
         if ((R_) == 4) { if (F_) { CALL(8, 4, true); } else { CALL(8, 4, false); } }            \
         else { if (F_) { CALL(8, 5, true); } else { CALL(8, 5, false); } }                      \
     } while (0)
-// (R = 6 -- 72-row tiles, images up to ~1230^2 -- needs 168 VGPRs + ~100 B of scratch inside the sweep loop: not instantiated;
+// (R = 6 -- 72-row tiles, images up to ~1230^2 -- needs 168 VGPRs + ~100 B of scratch, which lands in the halo exchange: 1152^2
+// 652 G against 704 G on tall tiles: not instantiated;
 // R = 3 -- 36-row tiles -- is no faster than 8 waves x 4 rows, see plan_blocked_pass)
 static const int WGS_ROWS[] = {4, 5};
 static bool wgs_has_R(int R) { for (int r : WGS_ROWS) if (r == R) return true; return false; }
