@@ -241,6 +241,10 @@ def test_driver_input_errors_without_gpu(built, tmp_path):
     _write_input(tmp_path / "amp.txt", Phases=2, MeshAmpX=0)
     r = subprocess.run([EXE, str(tmp_path / "amp.txt")], capture_output=True, text=True)
     assert r.returncode == 1 and "MeshIncrease" in r.stderr
+    r = subprocess.run([EXE, "--precond-maxiter", "0"], capture_output=True, text=True)
+    assert r.returncode == 2 and "--precond-maxiter" in r.stderr
+    r = subprocess.run([EXE, "--help"], capture_output=True, text=True)
+    assert "--prefetch-threads" in r.stdout and "--precond-maxiter" in r.stdout
 
 
 def test_front_end_survives_damaged_input_under_sanitizers(tmp_path):

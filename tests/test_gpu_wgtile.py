@@ -870,3 +870,13 @@ def test_resident_fallback_in_stacks_and_streams(pkg, oracle):
         it, deff, conv, x, _, _ = want[k]
         assert (out[k].iters, out[k].deff_raw, out[k].conv) == (it, deff, conv)
         assert_field(out[k].field, x)
+
+
+def test_cooperative_launch_mode_is_gone(pkg):
+    """tb_launch = 2 (hipLaunchCooperativeKernel) crashed in the ROCm runtime's teardown with several launching threads and is
+    no longer part of the tuning surface: the key takes 0 or 1."""
+    with pkg.Solver(64, 64) as s:
+        s.set_tuning("tb_launch", 1)
+        s.set_tuning("tb_launch", 0)
+        with pytest.raises(pkg.DeffError, match="tb_launch takes"):
+            s.set_tuning("tb_launch", 2)
