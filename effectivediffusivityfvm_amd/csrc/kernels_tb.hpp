@@ -616,9 +616,6 @@ __global__ __launch_bounds__(256, (T >= 6 ? 3 : 1)) void k_sweep_matfree_tb(cons
 // counters (rows produced / rows consumed), LDS operations of one wave execute in order, and both waves run the same
 // number of steps over the same tiles, so every wait is for a row the partner is certain to produce / consume.
 // Same arithmetic per cell as tb_strip -- the levels are just dealt to two waves -- so the same bits.
-#ifndef TB2_MINW
-#define TB2_MINW 4
-#endif
 constexpr int TB2_RING = 8;                                    // level-T/2 rows in flight between the two waves of a pair
 struct Tb2Shared {
     double2 x[4][TB2_RING][64];
@@ -773,7 +770,7 @@ __device__ __forceinline__ void tb_strip_half(const double *lut, const uint16_t 
 // grid: persistent workgroups of 8 waves = 4 pairs; wave tiles are numbered and dealt exactly as in k_sweep_matfree_tb (4 per
 // workgroup), wave w and wave w + 4 share tile w (A = the lower one).
 template <int T, bool FMA, bool GUARD>
-__global__ __launch_bounds__(512, TB2_MINW) void k_sweep_matfree_tb2(const double *__restrict__ lut_g,
+__global__ __launch_bounds__(512, 4) void k_sweep_matfree_tb2(const double *__restrict__ lut_g,
                                                           const uint16_t *__restrict__ code,
                                                           const double *__restrict__ x,
                                                           double *__restrict__ xnew, int nx, int ny,
@@ -791,11 +788,7 @@ __global__ __launch_bounds__(512, TB2_MINW) void k_sweep_matfree_tb2(const doubl
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#ifdef TB2_FORCE_ROLE
-    const int pair = wave & 3, role = TB2_FORCE_ROLE;
-#else
     const int pair = wave & 3, role = wave >> 2;
-#endif
     const unsigned total = (unsigned)nbt;
     const unsigned wtiles = (unsigned)ntx * (unsigned)gy;
     const unsigned per = (total + 7u) / 8u;
