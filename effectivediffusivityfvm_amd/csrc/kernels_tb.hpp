@@ -107,13 +107,13 @@ __device__ __forceinline__ double tb_cell(const double *lut, unsigned off, doubl
 #endif
 //   TB_BUF 1 = rows are addressed as buffer base (per wave tile, SGPRs) + lane offset (one VGPR) + row offset (an SGPR)
 //   instead of 64-bit pointers computed per row in VALU (10 VALU instructions per step, 12 VGPRs of addresses).
-//   (2 = in addition, what must not be read or written is addressed out of range -- loads return 0, stores are dropped --
-//   instead of being selected afterwards / branched around: the step becomes one basic block.)
 //   TB_SPLIT 1 = the two 16-bit codes of a lane's cells travel down the levels as two registers, split once per input row,
 //   instead of one register split at every level (2 VALU instructions per level saved, T + 1 VGPRs spent).
 //   Measured at 4096^2, one process per comparison (profiles/r03_tb_ab_kbench.log; all of them bit-exact on the parity suite):
 //   fence in the middle 1 109-1 115 against 1 112-1 116 G; TB_BUF 1 +0.7 %; TB_BUF 1 + TB_SPLIT + fence in the middle +1.7 %
-//   with 4.4 % fewer VALU instructions per launch (profiles/r03_tb_sq_counters_fewer_valu_midfence.json); TB_BUF 2 +1.6...2.9 %.
+//   with 4.4 % fewer VALU instructions per launch (profiles/r03_tb_sq_counters_fewer_valu_midfence.json).  (A further form that
+//   addressed everything not to be read or written OUT OF RANGE of the buffer -- loads return 0, stores are dropped, no branch
+//   around the store -- measured -1...+3 % and failed the row-slab parity test: removed.)
 //   None is the default: the kernel is not short of issue slots, and the buffer forms need the wave
 //   tile's window to stay below 2 GiB, which the pointer form does not.
 #ifndef TB_BUF
@@ -327,20 +327,6 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
     const __amdgpu_buffer_rsrc_t bc = tb_rsrc(code + (size_t)rbase * nx, span * 2u);
     const __amdgpu_buffer_rsrc_t bo = tb_rsrc(xnew + (size_t)rbase * nx, span * 8u);
     const unsigned vcol = (unsigned)(in_x ? col : 0);
-#if TB_BUF >= 2
-    // TB_BUF 2: what must not be read or written is addressed OUT OF RANGE instead of being branched around or selected
-    // afterwards -- a buffer load beyond num_records returns 0 (exactly the value of a cell outside the mesh and the code of
-    // the zero row), a store beyond it is dropped: no exec-mask branch around the store, no selects behind the loads.
-    constexpr unsigned OOB = 0x80000000u;
-    const unsigned vx_in = in_x ? vcol * 8u : OOB, vc_in = in_x ? vcol * 2u : OOB, vx_st = st_x ? vcol * 8u : OOB;
-    auto fetch = [&](const int rr, double2 &vx_out, unsigned &vc_out) __attribute__((always_inline)) {
-        const bool rok = rr >= row_lo && rr < row_hi && rr < r_end;          // wave-uniform
-        const unsigned ro = (unsigned)((rok ? rr : rbase) - rbase) * (unsigned)nx;
-        const tb_u4 v = __builtin_amdgcn_raw_buffer_load_b128(bx, (int)(rok ? vx_in : OOB), (int)(ro * 8u), 0);
-        vc_out = __builtin_amdgcn_raw_buffer_load_b32(bc, (int)(rok ? vc_in : OOB), (int)(ro * 2u), 0);
-        __builtin_memcpy(&vx_out, &v, 16);
-    };
-#else
     auto fetch = [&](const int rr, double2 &vx_out, unsigned &vc_out) __attribute__((always_inline)) {
         const bool rok = rr >= row_lo && rr < row_hi && rr < r_end;          // wave-uniform
         const unsigned ro = (unsigned)((rok ? rr : rbase) - rbase) * (unsigned)nx;
@@ -352,7 +338,6 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
         vx_out = ok ? vx : zero;
         vc_out = ok ? vc : 0u;
     };
-#endif
 #else
     auto fetch = [&](const int rr, double2 &vx_out, unsigned &vc_out) __attribute__((always_inline)) {
         const bool ok = in_x && rr >= row_lo && rr < row_hi && rr < r_end;
@@ -408,7 +393,7 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
             cw[0] = cur_c[ph];
 #endif
             w[0][sS] = cur_x[ph];
-#if TB_PIPE && !TB_SPLIT && !TB_FAKE && TB_BUF < 2
+#if TB_PIPE && !TB_SPLIT && !TB_FAKE
             if constexpr (!TRIM && !GUARD) {
                 constexpr int PS = LUT_PLANE_STRIDE * 8;
                 TbCoef k;
@@ -497,16 +482,6 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
                     asm volatile("" :: "v"(nx_x[0].x), "v"(nx_x[0].y), "v"(nx_x[1].x), "v"(nx_x[1].y), "v"(nx_x[2].x),
                                  "v"(nx_x[2].y), "v"(nx_c[0]), "v"(nx_c[1]), "v"(nx_c[2]));
                 }
-#if TB_BUF >= 2 && !TB_FAKE
-                if (t < T) {
-                    w[t][sS] = o;
-                } else {
-                    tb_u4 ov;
-                    __builtin_memcpy(&ov, &o, 16);
-                    const bool srok = rt >= ry0 && rt < ry1;                     // wave-uniform
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, bo, (int)(srok ? vx_st : OOB), (int)((unsigned)((srok ? rt : rbase) - rbase) * (unsigned)nx * 8u), 0);
-                }
-#else
                 if (t < T) {
                     w[t][sS] = o;
                 } else if (st_x && rt >= ry0 && rt < ry1) {
@@ -520,7 +495,6 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
                     st2(xnew + (size_t)rt * nx + col, o);
 #endif
                 }
-#endif
                 // keep the scheduler from pulling the next sweeps' table lookups up here: left
                 // alone it hoists them all (180-250 VGPRs, 1-2 waves per SIMD); with the fence a
                 // step keeps ~120 VGPRs and 4 waves per SIMD hide the LDS latency instead
