@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mcells*iter/s of the Jacobi sweep at 4096^2 on MI355X.
 
-  python bench.py [--gpus N --steps K --warmup W]
+  python bench.py [--gpus N --steps K --warmup W]      (N > 1: starts its own N ranks as child processes)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = `--sweeps-per-step` weighted-Jacobi sweeps plus one Deff evaluation
@@ -275,6 +275,47 @@ def bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier, use_dis
         dist.destroy_process_group()
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a CHILD process (the form the driver itself
+    uses), pass its output through and return its exit code.  The parent has not imported torch and never touches the
+    GPU, and nothing is exec'ed: every rank is a fresh process."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_dry(world, rank, local_rank):
+    """--launch-dry: prove the launcher without GPUs.  Every rank joins a gloo group on the rendezvous the launcher set
+    up, the ranks gather (rank, world, local_rank, pid, parent pid) and rank 0 prints them as one JSON line."""
+    import datetime
+    import torch.distributed as dist
+    if world > 1 or "MASTER_ADDR" in os.environ:
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+        every = [None] * world
+        dist.all_gather_object(every, {"rank": rank, "world": world, "local_rank": local_rank, "pid": os.getpid(),
+                                       "ppid": os.getppid()})
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        every = [{"rank": rank, "world": world, "local_rank": local_rank, "pid": os.getpid(), "ppid": os.getppid()}]
+    if rank == 0:
+        print(json.dumps({"launch_dry": True, "n_gpus": world, "ranks": every}), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -302,21 +343,31 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per GPU swept together (dataset-generation mode)")
     ap.add_argument("--slabs", type=int, default=1, help="--mode slab on ONE GPU: split the image into this many slabs "
                                                          "(one process, peer copies) and report the exchange's exposed time")
+    ap.add_argument("--launch-dry", action="store_true", help="start the ranks, join a gloo group, report rank/world and "
+                                                              "exit: the launcher's test (no GPU needed)")
     args = ap.parse_args()
     if args.primary_only:
         args.no_cpu_baseline = args.no_small_image = args.no_live_traffic = args.no_live_stats = args.no_iters_to_tol = True
         args.explicit_sweeps = 0
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes a launcher and nothing else (it never imports torch or
+        # touches HIP); the N ranks are fresh children of a torch.distributed.run child
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
+    if args.launch_dry:
+        return launch_dry(world, rank, local_rank)
 
     import torch  # first: one HIP runtime for torch and libdeff_amd
     import torch.distributed as dist
+
+    ndev = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if local_rank >= ndev:
+        sys.exit(f"bench.py rank {rank}: device {local_rank} of {ndev} (this box has fewer GPUs than --gpus {world}; "
+                 "there is no CPU fallback)")
     import effectivediffusivityfvm_amd as pkg
 
     if not torch.cuda.is_available():

@@ -1,0 +1,74 @@
+"""`python bench.py --gpus N` must start its own N ranks: the parent stays a launcher that never
+imports torch or touches the GPU, the ranks are fresh children of a `python -m torch.distributed.run` child -- the form the
+driver itself uses for N > 1.  Proven here without GPUs: --launch-dry brings the ranks up on a gloo group; without it, on
+a box with fewer GPUs than asked, the refusal comes from the ranks themselves, not from argument parsing."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT") and not k.startswith("TORCHELASTIC_")}
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def _json_line(text):
+    for line in text.splitlines():
+        if line.startswith("{"):
+            return json.loads(line)
+    raise AssertionError("no JSON line in:\n" + text)
+
+
+@pytest.mark.parametrize("mode", ["images", "slab"])
+def test_gpus_2_starts_two_fresh_ranks(mode):
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-dry", "--mode", mode], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = _json_line(r.stdout)
+    assert out["launch_dry"] and out["n_gpus"] == 2
+    ranks = out["ranks"]
+    assert [(x["rank"], x["world"], x["local_rank"]) for x in ranks] == [(0, 2, 0), (1, 2, 1)]
+    assert len({x["pid"] for x in ranks}) == 2                 # two processes ...
+    assert len({x["ppid"] for x in ranks}) == 1                # ... children of ONE launcher child, not of each other
+
+
+def test_launch_dry_under_the_drivers_own_launcher():
+    """The driver's form: torch.distributed.run around bench.py; the self-launch must stay out of the way."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--launch-dry"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = _json_line(r.stdout)
+    assert [x["rank"] for x in out["ranks"]] == [0, 1]
+
+
+def test_gpus_1_needs_no_launcher():
+    r = subprocess.run([sys.executable, BENCH, "--launch-dry"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 1 and out["ranks"][0]["rank"] == 0
+
+
+def test_too_few_gpus_is_reported_by_the_ranks():
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev >= 2:
+        pytest.skip("this box has the GPUs")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert f"rank 1: device 1 of {ndev}" in r.stderr, r.stderr
+    assert "must be launched with" not in r.stderr
