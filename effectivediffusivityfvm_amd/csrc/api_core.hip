@@ -237,6 +237,7 @@ extern "C" int deff_set_tuning(deff_ctx *c, const char *key, int value)
 try {
     if (!c || !key) return fail(DEFF_EINVAL, "NULL argument");
     if (value < 0) return fail(DEFF_EINVAL, "tuning value must be >= 0");
+    if (c->res_pending) { TRY(use_device(c)); TRY(resident_check(c)); }   // before arithmetic / plan / test hooks change
     if (!strcmp(key, "rows_explicit")) c->rows_explicit = value;
     else if (!strcmp(key, "rows_matfree")) c->rows_matfree = value;
     else if (!strcmp(key, "wg_matfree")) c->wg_matfree = (value + 7) / 8 * 8;
@@ -303,6 +304,7 @@ extern "C" int deff_set_image(deff_ctx *c, const uint8_t *pix, int W, int H, int
 try {
     if (!c || !pix) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
+    TRY(resident_check(c));                          // an unchecked resident interval is settled under the OLD field / system
     TRY(image_shape(c, W, H, ampX, ampY));
     HIP_TRY(hipMemcpyAsync(c->pix, pix, (size_t)W * H * c->nimg, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -316,6 +318,7 @@ extern "C" int deff_synth_image(deff_ctx *c, uint64_t seed, uint64_t img)
 try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     TRY(use_device(c));
+    TRY(resident_check(c));                          // an unchecked resident interval is settled under the OLD field / system
     TRY(image_shape(c, c->nxt, c->ny, 1, 1));
     // stacked rows continue the per-pixel key, so a batch holds images img, img+1, ...
     hipLaunchKernelGGL(k_synth_mask, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->pix, c->nxt, c->ny,
@@ -389,6 +392,7 @@ try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     if (!c->have_image) return fail(DEFF_ESTATE, "deff_assemble_2phase needs an image");
     TRY(use_device(c));
+    TRY(resident_check(c));                          // an unchecked resident interval is settled under the OLD field / system
     TRY(ensure_walls(c));
     c->CL = CL; c->CR = CR;
     hipLaunchKernelGGL(k_wall_D_2phase, dim3((c->rows + 255) / 256), dim3(256), 0, c->stream, c->pix, c->W,
@@ -445,6 +449,7 @@ try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     if (!c->have_image) return fail(DEFF_ESTATE, "deff_assemble_3phase needs an image");
     TRY(use_device(c));
+    TRY(resident_check(c));                          // an unchecked resident interval is settled under the OLD field / system
     TRY(ensure_explicit(c));
     TRY(ensure_walls(c));
     const size_t bytes = sizeof(double) * c->n + (Grid ? sizeof(unsigned int) * c->n : 0);
@@ -511,6 +516,7 @@ extern "C" int deff_assemble_from_D(deff_ctx *c, const double *D, const unsigned
 try {
     if (!c || !D) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
+    TRY(resident_check(c));                          // an unchecked resident interval is settled under the OLD field / system
     TRY(ensure_explicit(c));
     TRY(ensure_walls(c));
     const size_t bytes = sizeof(double) * c->n + (Grid ? sizeof(unsigned int) * c->n : 0);
@@ -538,6 +544,7 @@ extern "C" int deff_set_system(deff_ctx *c, const double *A, const double *b, co
 try {
     if (!c || !A || !b) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
+    TRY(resident_check(c));                          // an unchecked resident interval is settled under the OLD field / system
     // W link of a first-column cell / E link of a last-column cell: never produced by the reference's assembly
     // (cuh:849-864), but a caller-built A may hold one; see deff_ctx::wrap_links
     bool wrap = false;
@@ -630,6 +637,7 @@ extern "C" int deff_init_linear(deff_ctx *c, double CL, double CR)
 try {
     if (!c) return fail(DEFF_EINVAL, "ctx is NULL");
     TRY(use_device(c));
+    TRY(resident_check(c));                          // an unchecked resident interval is settled under the OLD field / system
     hipLaunchKernelGGL(k_init_linear, dim3(grid_for(c->n)), dim3(256), 0, c->stream, c->x[c->cur], c->nx,
                        c->nxt, c->rows, CL, CR, c->fma);
     HIP_TRY(hipGetLastError());
@@ -661,6 +669,7 @@ extern "C" int deff_set_field(deff_ctx *c, const double *x)
 try {
     if (!c || !x) return fail(DEFF_EINVAL, "NULL argument");
     TRY(use_device(c));
+    TRY(resident_check(c));                          // an unchecked resident interval is settled under the OLD field / system
     TRY(rows_h2d(c, c->x[c->cur], x, (size_t)c->rows));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_field = true;

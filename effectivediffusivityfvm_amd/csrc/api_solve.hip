@@ -1314,6 +1314,7 @@ try {
             for (int k = 0; k < B; ++k)
                 if (S[k].live && S[k].iters >= max_iter) { hit = true; }
             if (hit) {
+                TRY(resident_check(c));                // the retired images' fields are handed out now: settle the interval first
                 HIP_TRY(hipEventRecord(c->ev1, c->stream));
                 HIP_TRY(hipEventSynchronize(c->ev1));
                 float ms2 = 0;
@@ -1332,6 +1333,7 @@ try {
             if (c->links_sym != 1) { pl = SweepPlan(); TRY(plan_sweeps(c, omega, &pl)); }   // (never for the native assembly)
         }
     }
+    TRY(resident_check(c));                            // nothing unchecked outlives the stream's mask and slots
     c->masked = false;
     reset_batch_state(c);
     return DEFF_OK;
@@ -1373,6 +1375,7 @@ try {
     (void)hipFree(c->tb_stamps);
     c->tb_stamps = nullptr;
     if (e != hipSuccess) return fail(DEFF_EHIP, "stamp readback failed: %s", hipGetErrorString(e));
+    TRY(resident_check(c));
     return DEFF_OK;
 }
 DEFF_API_CATCH

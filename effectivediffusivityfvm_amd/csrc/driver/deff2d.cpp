@@ -456,7 +456,10 @@ class Prefetcher {
 public:
     Prefetcher(Shared *sh, size_t depth, int threads = 1) : sh_(sh), depth_(depth), running_(threads < 1 ? 1 : threads)
     {
-        for (int t = 0; t < running_; ++t) th_.emplace_back([this] { run(); });
+        // the count is fixed before the first thread exists: a thread that finds no work decrements running_ (leave())
+        // while its siblings are still being started
+        const int n = running_;
+        for (int t = 0; t < n; ++t) th_.emplace_back([this] { run(); });
     }
     ~Prefetcher()
     {

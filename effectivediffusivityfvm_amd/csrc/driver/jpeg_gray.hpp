@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -267,8 +268,27 @@ inline bool progressive_scan(BitReader &br, int16_t *coef, size_t nblocks, const
 
 // Returns true on success.  ncomp is set as soon as the frame header is seen, so a caller can
 // report "n channels" for files that are not grayscale (the reference's check, cuh:1665).
+inline bool decode_gray_impl(const uint8_t *data, size_t len, std::vector<uint8_t> &pix, int &w, int &h, int &ncomp,
+                             std::string &err);
+
+// the largest image accepted: 2^28 pixels (16384^2, the largest mesh of the benchmark configurations).  A progressive file
+// keeps 128 B of coefficients per 64-pixel block over all its scans, so the bound also caps what a small crafted file can
+// make the decoder allocate (2 B per pixel); an allocation failure is a decode error, not an exception.
+constexpr uint64_t MAX_PIXELS = (uint64_t)1 << 28;
+
 inline bool decode_gray(const uint8_t *data, size_t len, std::vector<uint8_t> &pix, int &w, int &h, int &ncomp,
                         std::string &err)
+{
+    try {
+        return decode_gray_impl(data, len, pix, w, h, ncomp, err);
+    } catch (const std::bad_alloc &) {
+        err = "out of memory while decoding";
+        return false;
+    }
+}
+
+inline bool decode_gray_impl(const uint8_t *data, size_t len, std::vector<uint8_t> &pix, int &w, int &h, int &ncomp,
+                             std::string &err)
 {
     w = h = ncomp = 0;
     if (len >= 8 && !memcmp(data, "\x89PNG\r\n\x1a\n", 8)) {
@@ -350,6 +370,7 @@ inline bool decode_gray(const uint8_t *data, size_t len, std::vector<uint8_t> &p
             w = (seg[3] << 8) | seg[4];
             ncomp = seg[5];
             if (w <= 0 || h <= 0) { err = "zero-sized image"; return false; }
+            if ((uint64_t)w * (uint64_t)h > MAX_PIXELS) { err = "image larger than 2^28 pixels"; return false; }
             if (ncomp != 1) { err = "not a single-channel (grayscale) JPEG"; return false; }
             if (n < 9) { err = "bad SOF"; return false; }
             qid = seg[8] & 3;

@@ -211,6 +211,22 @@ def test_jpeg_decoder_rejects_what_the_reference_rejects(built, tmp_path):
     assert mine.shape == (37, 53) and np.abs(mine.astype(int) - ref.astype(int)).max() <= 1
 
 
+def test_jpeg_header_that_promises_a_huge_image_is_refused_before_allocating(built, tmp_path):
+    """a progressive file keeps 128 B per block over all scans, so a small crafted file whose frame header names
+    65535 x 65535 pixels must be refused by size (2^28 pixels is the cap), not by an allocation."""
+    import effectivediffusivityfvm_amd as pkg
+    from PIL import Image
+    p = tmp_path / "small.jpg"
+    Image.fromarray(np.zeros((16, 16), dtype=np.uint8)).save(p, progressive=True)
+    raw = bytearray(p.read_bytes())
+    i = raw.index(b"\xff\xc2")                        # SOF2: length(2) precision(1) height(2) width(2)
+    raw[i + 5:i + 9] = b"\xff\xff\xff\xff"
+    q = tmp_path / "huge.jpg"
+    q.write_bytes(bytes(raw))
+    with pytest.raises(pkg.DeffError, match="larger than 2\\^28 pixels"):
+        pkg.load_jpeg_gray(q)
+
+
 def test_input_file_parsing_matches_reference_conventions(built, tmp_path):
     """Keys with their colon, any order, numeric values through double (MaxIter: 5e5), unknown
     lines ignored (the decorative 'Input File:' header), file names as second token; defaults for

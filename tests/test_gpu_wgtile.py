@@ -872,6 +872,44 @@ def test_resident_fallback_in_stacks_and_streams(pkg, oracle):
         assert_field(out[k].field, x)
 
 
+def test_stream_that_ends_between_checks_settles_its_last_interval(pkg, oracle):
+    """a stream whose last images run into MAX_ITER between two checks used to return with its last
+    resident interval unchecked.  If that interval had given up, the images were handed out as they were, and the next
+    deff_sweeps() on the context restored the stale restart copy over the caller's new field.  Here the last interval (49
+    sweeps after the check at sweep 201) stalls: every image must still come out with the oracle's 250 sweeps, and a new
+    field set on the same context afterwards must be swept from THAT field."""
+    nx, ny = 250, 90
+    rng = np.random.default_rng(99)
+    pixs = [rand_mask(rng, nx, ny, 0.4 + 0.05 * k) for k in range(3)]
+    sys_ = []
+    for k in range(3):
+        D = oracle.fill_D_2phase(pixs[k], 1.0, 1e-2)
+        A, b = oracle.discretize(D, 0.0, 1.0)
+        sys_.append((A, b, D))
+    x0 = oracle.linear_guess(nx, ny, 0.0, 1.0)
+    want = [oracle.jacobi(A, b, x0, D, 0.0, 1.0, 1e-12, 250, check_every=200) for A, b, D in sys_]
+    with pkg.Solver(nx, ny, nimg=3, kernel="matfree_tb") as s:
+        s.set_tuning("tb_impl", 2)
+
+        def images():
+            yield from pixs
+            s.set_tuning("tb_debug_stall", 2)          # asked for a 4th image after the first interval: stall what follows
+        out = s.solve_stream(images(), 1e-2, 1.0, 0.0, 1.0, 1e-12, 250, check_every=200, want_fields=True)
+        assert s.plan_value("tb_fallbacks") == 1
+        for k in range(3):
+            it, deff, conv, x, _, _ = want[k]
+            assert it == 250 and (out[k].iters, out[k].deff_raw, out[k].conv) == (it, deff, conv)
+            assert_field(out[k].field, x)
+        # the same context, a new field: nothing of the stream's last interval may come back
+        xs = 0.25 + 0.5 * x0
+        s.set_field(np.tile(xs, (3, 1)))
+        s.sweeps(19)
+        got = s.get_field()
+        for k in range(3):
+            A, b, _ = sys_[k]
+            assert_field(got[k * ny:(k + 1) * ny], oracle.sweeps(A, b, xs, 19))
+
+
 def test_cooperative_launch_mode_is_gone(pkg):
     """tb_launch = 2 (hipLaunchCooperativeKernel) crashed in the ROCm runtime's teardown with several launching threads and is
     no longer part of the tuning surface: the key takes 0 or 1."""
