@@ -245,7 +245,10 @@ try {
     else if (!strcmp(key, "serpentine")) c->serpentine = value ? 1 : 0;
     else if (!strcmp(key, "tb_T")) c->tb_T = value;
     else if (!strcmp(key, "tb_LY")) c->tb_LY = value;
-    else if (!strcmp(key, "tb_impl")) c->tb_impl = value > 3 ? 0 : value;
+    else if (!strcmp(key, "tb_impl")) {
+        if (value > 2) return fail(DEFF_EINVAL, "tb_impl takes 0 (planner's choice), 1 (streaming) or 2 (workgroup tiles)");
+        c->tb_impl = value;
+    }
     else if (!strcmp(key, "tb_R")) c->tb_R = value;
     else if (!strcmp(key, "tb_debug_stall")) c->tb_debug_stall = value;
     else if (!strcmp(key, "tb_sym")) c->tb_sym = value;

@@ -37,25 +37,6 @@ static int tb_occ(int *per_cu)
         }                                                                                   \
     } while (0)
 
-// the paired-wave form (k_sweep_matfree_tb2, T = 8): workgroups of 8 waves
-template <bool F, bool G>
-static int tb2_occ(int *per_cu)
-{
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_sweep_matfree_tb2<8, F, G>, 512, 0));
-    return DEFF_OK;
-}
-
-static int tb2_resident_blocks(const deff_ctx *c, bool fma, bool guard, int *resident)
-{
-    int per_cu = 0, cus = 0;
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-    if (fma) { if (guard) TRY((tb2_occ<true, true>(&per_cu))); else TRY((tb2_occ<true, false>(&per_cu))); }
-    else { if (guard) TRY((tb2_occ<false, true>(&per_cu))); else TRY((tb2_occ<false, false>(&per_cu))); }
-    if (per_cu < 1) per_cu = 1;
-    *resident = per_cu * cus;
-    return DEFF_OK;
-}
-
 static int tb_resident_blocks(const deff_ctx *c, int T, bool fma, bool guard, int *resident)
 {
     int per_cu = 0, cus = 0;
@@ -360,7 +341,6 @@ int default_tb_T(const deff_ctx *c)
 {
     // workgroup tiles: 8 sweeps per pass amortise the launch gap and the first-load latency (1024^2: T = 8 556, T = 4 457)
     if ((c->tb_impl ? c->tb_impl : default_tb_impl(c)) == 2) return 8;
-    if (c->tb_impl == 3) return 8;                     // the paired-wave form exists for T = 8 only
     // streaming: below 4 Mi cells the launch is latency-bound and T = 4 wins; above, T = 8 everywhere (with the
     // prefetch really in flight, kernels_tb.hpp, stacks no longer prefer T = 6: 1 024 x 128^2 1 222 vs
     // 1 125 G cells*iter/s, 64 x 1024^2 1 258 vs 1 156, 16 x 1024^2 1 106 vs 1 064)
@@ -654,14 +634,12 @@ static int plan_sym(deff_ctx *c, SweepPlan *pl, int T, int own_h, int R)
 // halo-blind model picks.)
 static int plan_streaming(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int own_h)
 {
-    // tb_impl = 3: the levels of a tile dealt to a PAIR of waves (k_sweep_matfree_tb2; whole passes of T = 8 only)
-    pl->impl = (c->tb_impl == 3 && T == 8 && !pl->T_override && pl->band_h <= 0) ? 3 : 1;
+    pl->impl = 1;
     pl->resident = false;
     pl->guard = c->lut_guard;                          // the reference's non-zero link test matters only when a phase cannot diffuse
     int resident = c->tb_wg;
     if (!resident) {
-        if (pl->impl == 3) TRY(tb2_resident_blocks(c, pl->fma, c->lut_guard, &resident));
-        else TRY(tb_resident_blocks(c, T, pl->fma, c->lut_guard, &resident));
+        TRY(tb_resident_blocks(c, T, pl->fma, c->lut_guard, &resident));
     }
     int LY = c->tb_LY;
     if (!LY) {
@@ -719,7 +697,7 @@ static int plan_blocked_pass(deff_ctx *c, SweepPlan *pl)
     plan_strips(c, T, pl);
     int tall_R = 0, sym_R = 0;
     TRY(choose_tall_R(c, pl, T, own_h, &tall_R));
-    int want_impl = c->tb_impl ? (c->tb_impl == 3 ? 1 : c->tb_impl) : default_tb_impl(c);
+    int want_impl = c->tb_impl ? c->tb_impl : default_tb_impl(c);
     // a context just above the 4 Mi cells where the streaming form takes over still runs faster on tall tiles when they fit
     if (!c->tb_impl && want_impl == 1 && tall_R) want_impl = 2;
     // workgroup tiles exist for T = 4 and 8; slabs' T = 1 remainder passes and the other T stay on the streaming kernel
@@ -874,18 +852,6 @@ int launch_tb_pass(deff_ctx *c, const SweepPlan &pl)
                        c->lut_nrows, pl.shift, pl.omw, c->tb_stamps)
         WGT_DISPATCH(pl.T, pl.R, pl.fma, pl.guard, LAUNCH_WGT);
 #undef LAUNCH_WGT
-        HIP_TRY(hipPeekAtLastError());
-        return DEFF_OK;
-    }
-    if (pl.impl == 3) {
-#define LAUNCH_TB2(C_, G_)                                                                                     \
-    hipLaunchKernelGGL((k_sweep_matfree_tb2<8, C_, G_>), dim3(pl.tblocks), dim3(512), 0, c->stream, c->lut,    \
-                       c->code, xin, xout, c->nx, c->mesh_ny, c->ny, c->dom_lo, pl.own_lo, pl.own_h, pl.tcpi, \
-                       mask, pl.LY, pl.ntx, pl.tgx, pl.tgy, flip, c->tb_xmajor,                              \
-                       (c->lut_allb || c->nx != c->nxt) ? 1 : 0, c->lut_nrows, pl.shift, pl.omw, c->tb_stamps)
-        if (pl.fma) { if (pl.guard) LAUNCH_TB2(true, true); else LAUNCH_TB2(true, false); }
-        else { if (pl.guard) LAUNCH_TB2(false, true); else LAUNCH_TB2(false, false); }
-#undef LAUNCH_TB2
         HIP_TRY(hipPeekAtLastError());
         return DEFF_OK;
     }

@@ -81,7 +81,7 @@ int deff_get_kernel(const deff_ctx *ctx, int *kernel_in_use);
 /* tuning knob; 0 restores the default.  Keys: "rows_explicit", "rows_matfree", "wg_matfree",
  * "nt_explicit", "serpentine", "tb_T" (sweeps per pass: 1,2,4,6,8), "tb_LY" (rows per chunk), "tb_wg",
  * "tb_xmajor", "tb_wall_halo", "dict" (harvest a row dictionary from explicit systems: 1 default),
- * "tb_impl" (1 streaming, 2 workgroup tiles, 3 streaming with a pair of waves per tile), "tb_R", "tb_NW" (8 / 12 / 16 waves per
+ * "tb_impl" (1 streaming, 2 workgroup tiles), "tb_R", "tb_NW" (8 / 12 / 16 waves per
  *   tile: 12 = link-symmetric matrix rows in registers, 16 = tall resident tiles),
  * "tb_launch" (workgroup tiles whose tiles all fit the chip
  *   run every pass between two checks in ONE launch, neighbouring tiles synchronised by flags: 1 = one launch per
@@ -106,7 +106,8 @@ int deff_synth_image(deff_ctx *ctx, uint64_t seed, uint64_t img);   /* generated
 int deff_get_image(deff_ctx *ctx, uint8_t *pix);                    /* W*H bytes back */
 
 /* grayscale JPEG file -> bytes: replaces readImage cuh:327-345 (stbi_load(..., 1)); decodes to the
- * same bytes as stb_image v2.26 for baseline one-component files; *pix is malloc'ed, release it
+ * same bytes as stb_image v2.26 for one-component files, Huffman-coded baseline, extended sequential
+ * and progressive (images up to 2^28 pixels; PNG / BMP get a message); *pix is malloc'ed, release it
  * with deff_free(); host code, needs no context */
 int deff_load_jpeg_gray(const char *path, uint8_t **pix, int *W, int *H, int *nChannels);
 void deff_free(void *p);

@@ -52,12 +52,9 @@ def test_streaming_blocked_kernel_keeps_its_waves(usage):
         assert u["LDS"] <= 25 * 1024, (name, u)                 # dictionary only: 3-4 workgroups per CU
 
 
-def test_paired_wave_kernel_fits_four_waves_per_simd(usage):
-    """k_sweep_matfree_tb2<8, FMA, GUARD>: 8 waves per workgroup (4 pairs), 128 VGPRs = 4 waves per SIMD, at most a few spilled
-    registers, LDS = dictionary + 40 KiB of rings: two workgroups per CU."""
-    for name, u in kernels(usage, "_ZN4deff19k_sweep_matfree_tb2ILi8E").items():
-        assert u["Occupancy"] >= 4 and u["VGPRs"] <= 128 and u["AGPRs"] == 0 and u["ScratchSize"] <= 32, (name, u)
-        assert u["LDS"] <= 80 * 1024, (name, u)
+def test_experiment_kernels_are_not_in_the_library(usage):
+    """The paired-wave form and the A/B branches of round 3 live in tools/experiments/, not in the shipped translation unit."""
+    assert not [k for k in usage if "matfree_tb2" in k]
 
 
 def test_workgroup_tile_kernel_fits_two_waves_per_simd(usage):
