@@ -124,6 +124,7 @@ try {
     for (void *p : bufs) if (p) (void)hipFree(p);
     if (c->mf_host) (void)hipHostFree(c->mf_host);
     if (c->q) (void)hipFree(c->q);
+    if (c->resid) (void)hipFree(c->resid);
     if (c->res_flags) (void)hipFree(c->res_flags);
     if (c->res_abort) (void)hipFree(c->res_abort);
     if (c->res_backup) (void)hipFree(c->res_backup);
@@ -251,6 +252,8 @@ try {
     }
     else if (!strcmp(key, "tb_R")) c->tb_R = value;
     else if (!strcmp(key, "tb_debug_stall")) c->tb_debug_stall = value;
+    else if (!strcmp(key, "tb_debug_stall_skip")) c->tb_debug_stall_skip = value;
+    else if (!strcmp(key, "res_kt")) c->res_kt = value;
     else if (!strcmp(key, "tb_sym")) c->tb_sym = value;
     else if (!strcmp(key, "tb_launch")) {            // 0: resident passes where possible; 1: one launch per pass
         if (value > 1) return fail(DEFF_EINVAL, "tb_launch takes 0 (resident passes where the tiles fit the chip) or 1 (one launch per pass)");
@@ -372,6 +375,8 @@ int upload_lut(deff_ctx *c, double omega)
     if (c->lut_omega == omega) return DEFF_OK;
     std::vector<double> t(LUT_DOUBLES, 0.0);
     bool guard = false;
+    // (k starts at 1: row 0 -- the code of every cell outside the mesh -- stays all zeros in every plane, c0 included; the
+    // symmetric tile forms rely on it, kernels_wgtile.hpp: wgs_lookup)
     for (int k = 1; k < c->lut_nrows; ++k) {
         const double *row = &c->lut_rows[(size_t)k * 6];
         const double c0 = omega / row[0];
@@ -415,6 +420,7 @@ try {
 
     // the explicit SoA planes are built on demand (explicit_from_image)
     c->Ds = Ds; c->Df = Df;
+    c->phase_mode = 2; c->phase_D[0] = Df; c->phase_D[1] = Ds; c->phase_D[2] = 0.0;
     c->have_explicit = false;
     return DEFF_OK;
 }
@@ -473,6 +479,7 @@ try {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));        // Grid may be freed by the caller
     c->have_explicit = true; c->c0_omega = NAN; c->have_walls = true;
+    c->phase_mode = 3; c->phase_D[0] = Df; c->phase_D[1] = Ds; c->phase_D[2] = Dg;
     c->have_matfree = false; c->dict_tried = false; c->wrap_links = false;
     return DEFF_OK;
 }
@@ -537,6 +544,7 @@ try {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_explicit = true; c->c0_omega = NAN; c->have_walls = true;
+    c->phase_mode = 0;
     c->have_matfree = false; c->dict_tried = false; c->wrap_links = false;
     return DEFF_OK;
 }
@@ -574,6 +582,7 @@ try {
                            c->rows, soa_of(c));
         HIP_TRY(hipGetLastError());
     }
+    c->phase_mode = 0;
     c->CL = CL; c->CR = CR;
     c->have_walls = false;
     if (D) {

@@ -238,6 +238,7 @@ static hipError_t launch_resident(deff_ctx *c, const SweepPlan &pl, Kernel kerne
     unsigned long long *stamps = c->tb_stamps;
     unsigned xbytes = (unsigned)(c->n * sizeof(double));
     int stall_tile = c->tb_debug_stall - 1;
+    if (stall_tile >= 0 && c->tb_debug_stall_skip > 0) { --c->tb_debug_stall_skip; stall_tile = -1; }   // tests: a LATER launch stalls
     const double *lut = c->lut;
     const uint16_t *code = c->code;
     int nx = c->nx, ny = c->mesh_ny, img_stride = c->ny, dom_lo = c->dom_lo, own_lo = pl.own_lo, own_h = pl.own_h;
@@ -1182,6 +1183,7 @@ try {
     TRY(dev_alloc(&c->code, c->n));
     const int B = c->nimg;
     c->CL = CL; c->CR = CR; c->Ds = Ds; c->Df = Df;
+    c->phase_mode = 2; c->phase_D[0] = Df; c->phase_D[1] = Ds; c->phase_D[2] = 0.0;
     build_lut_rows(c, Ds, Df, CL, CR);
     c->have_image = true; c->have_walls = true; c->have_matfree = true; c->have_explicit = false;
     c->links_sym = 0;

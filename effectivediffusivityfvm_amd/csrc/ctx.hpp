@@ -101,6 +101,13 @@ struct deff_ctx {
     bool wrap_links = false;
     double lut_omega = NAN;
     double Ds = 0, Df = 0;          // phase diffusivities of the native 2-phase system
+    // what deff_residual() needs to know about a system assembled from the image: 2 / 3 pixel classes (0 = the system came
+    // from a caller's D plane or matrix) and their diffusivities {fluid, solid, gas}
+    int phase_mode = 0;
+    double phase_D[3] = {0, 0, 0};
+    double *resid = nullptr;        // device: partial sums of the residual reduction + one sum per image
+    size_t resid_cap = 0;
+    int res_kt = 0;                 // tuning: tiles of 8 rows a wave of the residual kernel streams through (0 = planner)
 
     // wall data for the flux evaluation
     double *Dl = nullptr, *Dr = nullptr;
@@ -161,6 +168,7 @@ struct deff_ctx {
     int links_sym = 0;
     int tb_sym = 0;                              // tuning: 2 = never use the symmetric short-cut (A/B, tests)
     int tb_debug_stall = 0;                      // tests: tile (index + 1) that leaves a resident launch without publishing
+    int tb_debug_stall_skip = 0;                 // tests: ... after this many further resident launches
     int plan_resident = 0;                       // the last plan used resident passes
     unsigned *res_flags = nullptr;               // per tile: passes completed (epoch counter)
     size_t res_flags_n = 0;

@@ -531,6 +531,11 @@ struct WgsCoef {
     double2 aN0;        // N links of the wave's first row
 };
 
+// A row's N links are taken from the S links of the row above it in the wave (k.aS[r - 1]; the wave's first row keeps its own:
+// k.aN0).  When row r - 1 lies outside the image its code is 0, i.e. the dictionary's row 0, and that row is all zeros on the
+// device BY CONSTRUCTION, whatever was harvested: upload_lut() (api_core.hip) fills the table from k = 1 on over a zeroed
+// buffer.  The row's own N link is 0 there too (top row of an image: no N face, fvm_row.hpp), and the value it multiplies is
+// the 0 that rows outside the image hold, so the product is the same +0.
 template <int R, bool WALL>
 __device__ __forceinline__ void wgs_lookup(const double *lut, const unsigned (&cc)[R], WgsCoef<R> &k, double2 (&bb)[WALL ? R : 1])
 {

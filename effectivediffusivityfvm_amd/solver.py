@@ -238,6 +238,20 @@ class Solver:
         check(self._L.deff_flux(self._ctx, d, MFL.ctypes.data_as(C.c_void_p), MFR.ctypes.data_as(C.c_void_p)))
         return (d[0] if self.nimg == 1 else np.array(d[:])), MFL, MFR
 
+    def residual(self, D=None, CL=None, CR=None, timing=False):
+        """Residual() cuh:451-494 of the current field (mean |qW - qE + qN - qS| per cell): a float, or one per image.
+        D = None: the system assembled from the image; otherwise the diffusivity plane (rows, nx) with the wall values."""
+        r = (C.c_double * self.nimg)()
+        ms = C.c_float()
+        if D is None:
+            check(self._L.deff_residual(self._ctx, r, C.byref(ms)))
+        else:
+            D = np.ascontiguousarray(D, dtype=np.float64)
+            assert D.size == self.nx * self.rows
+            check(self._L.deff_residual_D(self._ctx, D, float(CL), float(CR), r, C.byref(ms)))
+        out = r[0] if self.nimg == 1 else np.array(r[:])
+        return (out, ms.value) if timing else out
+
     def set_progress(self, fn):
         """fn(iter, deff_raw, change) after every convergence check, or None."""
         if fn is None:

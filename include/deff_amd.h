@@ -172,6 +172,14 @@ int deff_set_progress(deff_ctx *ctx, deff_progress_fn fn, void *user);
  * time on the context's stream), and one flux / Deff evaluation (cuh:1252-1263) */
 int deff_sweeps(deff_ctx *ctx, int64_t n, double omega, float *ms);
 int deff_flux(deff_ctx *ctx, double *deff_raw /* [nimg] */, double *MFL, double *MFR);
+/* Residual() cuh:451-494 of the current field: r[k] = mean over the cells of image k of |qW - qE + qN - qS| (the reference
+ * defines it and leaves its two call sites, cuh:1121 and cuh:1266, commented out).  Every cell's term is the reference's
+ * arithmetic; the sum is a wavefront-level reduction in a fixed order (deterministic; ~1e-16 relative from the reference's
+ * serial row-major order).  deff_residual: systems assembled from the image (deff_assemble_2phase / _3phase; no D plane is
+ * read: 9 B per cell); deff_residual_D: any diffusivity plane D[ny*nx] (host), the reference's own call shape.  Both may be
+ * called from a deff_set_progress() callback.  *ms (may be NULL) = device time of the reduction.  Not for slab contexts. */
+int deff_residual(deff_ctx *ctx, double *r /* [nimg] */, float *ms);
+int deff_residual_D(deff_ctx *ctx, const double *D, double CL, double CR, double *r /* [nimg] */, float *ms);
 /* sweep-kernel launches issued by the last deff_sweeps()/deff_solve() and the sweeps one
  * temporally blocked launch performs (1 for the single-sweep kernels) */
 int deff_last_launches(const deff_ctx *ctx, int64_t *launches, int *sweeps_per_pass);

@@ -273,6 +273,51 @@ double oracle_flux_deff(const double *x, const double *D, int nx, int ny, double
     return qAvg / ((CR - CL));
 }
 
+/* cuh:451-494 Residual(): the L1 norm of the cells' flux imbalance divided by the cell count
+ * ("conservation of energy in this problem").  Dead code in the reference (its two call sites,
+ * cuh:1121 and cuh:1266, are commented out) but the only residual it defines; restated literally:
+ *  - horizontal faces: dy/(dx) * H(dx/2, dx/2, D[p], D[p+-1]) * difference, walls dy/(dx/2) * D[p] *
+ *    (c - CL) and (CR - c); evaluated left to right, i.e. ((dy/dx) * H) * diff;
+ *  - vertical faces use the SAME dy/dx and the same dx/2 weights (the reference's text, cuh:480-489),
+ *    with H's arguments in the order (D[row+-1], D[row]); top row qN = 0, bottom row qS = 0;
+ *  - R += fabs(qW - qE + qN - qS) over rows, then columns, ascending; R / (numCols*numRows).
+ * Nothing in /root/reference holds a value of it: parity of the HIP residual is to this restatement only. */
+double oracle_residual(const double *cmap, const double *D, int numRows, int numCols, double TL, double TR)
+{
+    double dx = 1.0 / numCols;
+    double dy = 1.0 / numRows;
+    double qE, qW, qS, qN;
+    double R = 0;
+    for (int row = 0; row < numRows; row++) {
+        for (int col = 0; col < numCols; col++) {
+            const size_t p = (size_t)row * numCols + col;
+            if (col == 0) {
+                qW = dy / (dx / 2) * D[p] * (cmap[p] - TL);
+                qE = dy / (dx) * oracle_whm(dx / 2, dx / 2, D[p], D[p + 1]) * (cmap[p + 1] - cmap[p]);
+            } else if (col == numCols - 1) {
+                qW = dy / (dx) * oracle_whm(dx / 2, dx / 2, D[p], D[p - 1]) * (cmap[p] - cmap[p - 1]);
+                qE = dy / (dx / 2) * D[p] * (TR - cmap[p]);
+            } else {
+                qW = dy / (dx) * oracle_whm(dx / 2, dx / 2, D[p], D[p - 1]) * (cmap[p] - cmap[p - 1]);
+                qE = dy / (dx) * oracle_whm(dx / 2, dx / 2, D[p], D[p + 1]) * (cmap[p + 1] - cmap[p]);
+            }
+            if (row == 0) {
+                qN = 0;
+                qS = dy / dx * oracle_whm(dx / 2, dx / 2, D[p + numCols], D[p]) * (cmap[p + numCols] - cmap[p]);
+            } else if (row == numRows - 1) {
+                qS = 0;
+                qN = dy / dx * oracle_whm(dx / 2, dx / 2, D[p - numCols], D[p]) * (cmap[p] - cmap[p - numCols]);
+            } else {
+                qS = dy / dx * oracle_whm(dx / 2, dx / 2, D[p + numCols], D[p]) * (cmap[p + numCols] - cmap[p]);
+                qN = dy / dx * oracle_whm(dx / 2, dx / 2, D[p - numCols], D[p]) * (cmap[p] - cmap[p - numCols]);
+            }
+            R += fabs(qW - qE + qN - qS);
+        }
+    }
+    R = R / (numCols * numRows);
+    return R;
+}
+
 /* cuh:1163-1314 JacobiGPU (and cuh:1024-1160 JacobiGPUPreCond, which runs the
  * same loop): x is initial guess in, final field out.  Checks happen when
  * iter % check_every == 0 including iter 0, deffOld starts at the literal 5,

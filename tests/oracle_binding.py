@@ -66,6 +66,8 @@ def lib(flavour=None):
                                 C.c_double, C.c_long, C.c_long, _dp, _dp, _dp, C.c_int, C.c_double,
                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.oracle_jacobi.restype = C.c_long
+    L.oracle_residual.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double]
+    L.oracle_residual.restype = C.c_double
     L.oracle_floodfill.argtypes = [_u32p, C.c_int, C.c_int]
     L.oracle_floodfill.restype = C.c_int
     L.oracle_fracts_3d.argtypes = [_dp, C.c_long, C.c_double, C.c_double, C.POINTER(C.c_double),
@@ -155,6 +157,15 @@ def jacobi(A, b, x0, D, CL, CR, tol, max_iter, check_every=10000, kernel=0, omeg
                              np.ascontiguousarray(D), MFL, MFR, kernel, omega,
                              C.byref(deff), C.byref(conv))
     return it, deff.value, conv.value, x, MFL, MFR
+
+
+def residual(x, D, CL, CR, flavour=None):
+    """Residual(), cuh:451-494: mean over the cells of |qW - qE + qN - qS| for field x and diffusivities D (both (ny, nx))."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    D = np.ascontiguousarray(D, dtype=np.float64)
+    ny, nx = x.shape
+    assert D.shape == x.shape
+    return float(lib(flavour).oracle_residual(x, D, ny, nx, CL, CR))
 
 
 def floodfill(grid):

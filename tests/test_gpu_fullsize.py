@@ -64,6 +64,26 @@ def test_4096_blocked_sweeps_vs_oracle(pkg, oracle_4096, T):
         assert np.array_equal(MFL, oracle_4096["MFL"]) and np.array_equal(MFR, oracle_4096["MFR"])
 
 
+def test_4096_residual_vs_oracle(pkg, oracle, oracle_4096):
+    """Residual() cuh:451-494 at the benchmark's size: the wave-level reduction (no D plane read) and the plane kernel against
+    the oracle's serial sum over 16.7 M cells, <= 1e-12 relative; same bits on every call; device time reported."""
+    n = 4096
+    D = oracle.fill_D_2phase(oracle_4096["pix"], 1.0, 1e-3)
+    want = oracle.residual(oracle_4096["x27"], D, 0.0, 1.0)
+    with pkg.Solver(n, n, kernel="matfree_tb") as s:
+        s.synth_image(12345, 0)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(27)
+        got, ms = s.residual(timing=True)
+        assert abs(got - want) <= 1e-12 * want, (got, want)
+        best = min(s.residual(timing=True)[1] for _ in range(5))
+        assert all(s.residual() == got for _ in range(3))
+        assert abs(s.residual(D, 0.0, 1.0) - want) <= 1e-12 * want
+    print(f"residual 4096^2: {got!r} (oracle {want!r}), device time {best * 1e3:.1f} us")
+    assert best < 0.2                                      # one pass over x and the pixels: tens of microseconds
+
+
 def test_4096_contracted_and_explicit_vs_oracle(pkg, oracle, oracle_4096):
     """Same size: the explicit operator behind the seam (bit-equal to the oracle) and the contracted arithmetic
     (bit-equal to the oracle's -ffp-contract=fast build, inside the north-star tolerance of the default one)."""

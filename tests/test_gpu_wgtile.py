@@ -890,11 +890,11 @@ def test_stream_that_ends_between_checks_settles_its_last_interval(pkg, oracle):
     want = [oracle.jacobi(A, b, x0, D, 0.0, 1.0, 1e-12, 250, check_every=200) for A, b, D in sys_]
     with pkg.Solver(nx, ny, nimg=3, kernel="matfree_tb") as s:
         s.set_tuning("tb_impl", 2)
-
-        def images():
-            yield from pixs
-            s.set_tuning("tb_debug_stall", 2)          # asked for a 4th image after the first interval: stall what follows
-        out = s.solve_stream(images(), 1e-2, 1.0, 0.0, 1.0, 1e-12, 250, check_every=200, want_fields=True)
+        # the stream's resident launches: 199 sweeps between the checks at sweeps 1 and 201 (one launch), then the 49 sweeps up
+        # to MAX_ITER (the second launch): that one stalls
+        s.set_tuning("tb_debug_stall", 2)
+        s.set_tuning("tb_debug_stall_skip", 1)
+        out = s.solve_stream(pixs, 1e-2, 1.0, 0.0, 1.0, 1e-12, 250, check_every=200, want_fields=True)
         assert s.plan_value("tb_fallbacks") == 1
         for k in range(3):
             it, deff, conv, x, _, _ = want[k]
