@@ -29,7 +29,7 @@ SYMBOLS = [
     "deff_rccl_unique_id", "deff_slab_rank_create", "deff_slab_rank_create_custom", "deff_slab_rank_destroy", "deff_slab_rank_layout",
     "deff_slab_rank_window", "deff_slab_rank_context", "deff_slab_rank_set_tuning", "deff_slab_rank_set_image_window",
     "deff_slab_rank_synth_image", "deff_slab_rank_assemble_3phase", "deff_slab_group_assemble_3phase", "deff_slab_rank_get_field", "deff_slab_rank_sweeps", "deff_slab_rank_solve",
-    "deff_solve_stream", "deff_get_slot_field", "deff_debug_tb_stamps", "deff_flux", "deff_residual", "deff_residual_D", "deff_set_progress", "deff_last_launches", "deff_device_field", "deff_synchronize",
+    "deff_solve_stream", "deff_get_slot_field", "deff_debug_tb_stamps", "deff_flux", "deff_residual", "deff_residual_slot", "deff_residual_D", "deff_set_progress", "deff_last_launches", "deff_device_field", "deff_synchronize",
 ]
 
 
@@ -107,6 +107,7 @@ def load():
     L.deff_sweeps.argtypes = [ctx, C.c_int64, C.c_double, C.POINTER(C.c_float)]
     L.deff_flux.argtypes = [ctx, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
     L.deff_residual.argtypes = [ctx, C.POINTER(C.c_double), C.POINTER(C.c_float)]
+    L.deff_residual_slot.argtypes = [ctx, C.c_int, C.POINTER(C.c_double)]
     L.deff_residual_D.argtypes = [ctx, _dp, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_float)]
     L.deff_set_progress.argtypes = [ctx, PROGRESS_FN, C.c_void_p]
     L.deff_last_launches.argtypes = [ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int)]

@@ -55,6 +55,7 @@ struct Image {
 struct Row {                       // one output row (2-phase: porosity; 3-phase: SVF/LVF)
     std::string name;
     double porosity = 0, SVF = 0, LVF = 0, deff = NAN, seconds = 0, conv = NAN;
+    double residual = NAN;         // Residual() cuh:451-494 of the final field (--json only; the reference never prints it)
     int path = 0, nElements = 0;
     long iters = 0;
     std::vector<long> stages;
@@ -155,6 +156,7 @@ struct OneGpu {
         return true;
     }
     bool get_field(double *x) { CK(deff_get_field(S.ctx, x)); return true; }
+    bool residual(double *r) { CK(deff_residual(S.ctx, r, nullptr)); return true; }
     bool assemble3(const Options &o, double DCG, const unsigned int *grid)
     {
         CK(deff_assemble_3phase(S.ctx, o.DCsolid, o.DCfluid, DCG, grid, o.CLeft, o.CRight));
@@ -194,6 +196,7 @@ struct Slabs {
         return true;
     }
     bool get_field(double *x) { CK(deff_slab_group_get_field(g, x)); return true; }
+    bool residual(double *r) { *r = NAN; return true; }              // (the rows of the image live on several devices: not offered)
     bool assemble3(const Options &o, double DCG, const unsigned int *grid)
     {
         CK(deff_slab_group_assemble_3phase(g, o.DCsolid, o.DCfluid, DCG, grid, o.CLeft, o.CRight));
@@ -255,6 +258,7 @@ static bool solve_2phase(Target &&T, const Image &im, const Options &o, bool sin
         if (!stage(o.DCfluid)) return false;
     }
     row->seconds = ms_total / 1000.0;
+    if (!T.residual(&row->residual)) return false;
     if (field) { field->resize((size_t)nx * ny); if (!T.get_field(field->data())) return false; }
     return true;
 }
@@ -302,6 +306,7 @@ static bool solve_3phase(Target &&T, const Image &im, const Options &o, Row *row
     row->conv = r.conv;
     row->seconds = r.loop_ms / 1000.0;                                // JacobiGPUPreCond does not add to gpuTime, cuh:1147
     if (o.verbose == 1) std::printf("DCF = %g, Deff %g\n", DCF, row->deff);
+    if (!T.residual(&row->residual)) return false;
     if (field) { field->resize((size_t)nx * ny); if (!T.get_field(field->data())) return false; }
     return true;
 }
@@ -357,6 +362,9 @@ static bool solve_3phase_group(Session &S, const std::vector<Image> &ims, const 
         rows[k].seconds = res[k].loop_ms / 1000.0 / B;               // final stage only (cuh:1147), shared by the group
         if (o.verbose == 1) std::printf("Number%dDCF = %g, Deff %g\n", k, DCF, rows[k].deff);
     }
+    std::vector<double> rr(B);
+    CK(deff_residual(S.ctx, rr.data(), nullptr));
+    for (int k = 0; k < B; ++k) rows[k].residual = rr[k];
     if (fields) { fields->resize(ncell * B); CK(deff_get_field(S.ctx, fields->data())); }
     return true;
 }
@@ -409,6 +417,7 @@ static void write_json(const std::string &path, const Options &o, const std::vec
                      r.porosity, r.SVF, r.LVF, r.path);
         if (std::isfinite(r.deff)) std::fprintf(f, "\"Deff\": %.17g, ", r.deff); else std::fprintf(f, "\"Deff\": null, ");
         if (std::isfinite(r.conv)) std::fprintf(f, "\"converge\": %.17g, ", r.conv); else std::fprintf(f, "\"converge\": null, ");
+        if (std::isfinite(r.residual)) std::fprintf(f, "\"residual\": %.17g, ", r.residual); else std::fprintf(f, "\"residual\": null, ");
         std::fprintf(f, "\"iterations\": %ld, \"stage_iterations\": [", r.iters);
         for (size_t q = 0; q < r.stages.size(); ++q) std::fprintf(f, "%s%ld", q ? ", " : "", r.stages[q]);
         std::fprintf(f, "], \"Time\": %.9g, \"nElements\": %d}%s\n", r.seconds, r.nElements, k + 1 < rows.size() ? "," : "");
@@ -579,6 +588,7 @@ static void stream_done(void *user, int64_t id, int slot, const deff_result *r)
     row.stages.push_back((long)r->iters);
     row.seconds = r->loop_ms / 1000.0;                           // stream time when the image stopped
     if (o.verbose == 1) std::printf("Number%dDCF = %g, Deff %g\n", (int)id, o.DCfluid, row.deff);
+    if (deff_residual_slot(st.ctx, slot, &row.residual) != DEFF_OK) row.residual = NAN;
     progress_append(*st.sh->progress_path, (int)id, row);
     if (st.sh->want_field) {
         const int nx = st.W * o.MeshIncreaseX, ny = st.H * o.MeshIncreaseY;
@@ -598,7 +608,7 @@ static void progress_append(const std::string &path, int k, const Row &r)
     std::fprintf(f, "%d %a %a %a %a %a %a %d %d %ld %zu", k, r.porosity, r.SVF, r.LVF, r.deff, r.seconds, r.conv, r.path,
                  r.nElements, r.iters, r.stages.size());
     for (long st : r.stages) std::fprintf(f, " %ld", st);
-    std::fprintf(f, "\n");
+    std::fprintf(f, " %a\n", r.residual);
     std::fclose(f);
 }
 
@@ -626,6 +636,11 @@ static void progress_load(const std::string &path, std::vector<Row> &rows, std::
             p = e;
         }
         if (!ok) continue;
+        {
+            char *e = nullptr;                                   // the residual trails the stages (absent in older files: NaN)
+            const double v = std::strtod(p, &e);
+            if (e != p) r.residual = v;
+        }
         rows[(size_t)k] = r;
         done[(size_t)k] = 1;
     }

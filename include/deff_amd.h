@@ -179,6 +179,8 @@ int deff_flux(deff_ctx *ctx, double *deff_raw /* [nimg] */, double *MFL, double 
  * read: 9 B per cell); deff_residual_D: any diffusivity plane D[ny*nx] (host), the reference's own call shape.  Both may be
  * called from a deff_set_progress() callback.  *ms (may be NULL) = device time of the reduction.  Not for slab contexts. */
 int deff_residual(deff_ctx *ctx, double *r /* [nimg] */, float *ms);
+/* ... of ONE image of a stack, wherever its newest field lives: callable from the deff_image_done_fn callback of a stream */
+int deff_residual_slot(deff_ctx *ctx, int slot, double *r);
 int deff_residual_D(deff_ctx *ctx, const double *D, double CL, double CR, double *r /* [nimg] */, float *ms);
 /* sweep-kernel launches issued by the last deff_sweeps()/deff_solve() and the sweeps one
  * temporally blocked launch performs (1 for the single-sweep kernels) */

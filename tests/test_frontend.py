@@ -288,7 +288,7 @@ def test_front_end_survives_damaged_input_under_sanitizers(tmp_path):
 
 
 @pytest.mark.gpu
-def test_driver_2phase_batch_config1(built, tmp_path, recorded):
+def test_driver_2phase_batch_config1(built, tmp_path, recorded, oracle, img00000):
     """Config #1 through the command line: the reference's input.txt keys, 00000.jpg, RunBatch 1."""
     shutil.copy(os.path.join(GOLDEN, "00000.jpg"), tmp_path / "00000.jpg")
     _write_input(tmp_path / "input.txt", Phases=2, Ds="1e-3", Df=1, MeshAmpX=1, MeshAmpY=1, CR=1, CL=0,
@@ -315,6 +315,9 @@ def test_driver_2phase_batch_config1(built, tmp_path, recorded):
     field = np.fromfile(tmp_path / "field_00000_128x128.f64").reshape(128, 128)
     gold = np.load(os.path.join(GOLDEN, "img00000_field.npy"))
     assert np.linalg.norm(field - gold) / np.linalg.norm(gold) <= 1e-6 and np.array_equal(field, gold)
+    # --json also carries Residual() (cuh:451-494) of the final field: the oracle's value up to the order of the sum
+    want = oracle.residual(gold, oracle.fill_D_2phase(img00000, 1.0, 1e-3), 0.0, 1.0)
+    assert abs(res["residual"] - want) <= 1e-12 * want
 
 
 @pytest.mark.gpu
@@ -496,11 +499,13 @@ def test_driver_batch_groups_images(built, tmp_path, oracle):
     for k in range(7):
         D = oracle.fill_D_2phase(pixs[k], 1.0, 1e-2)
         A, b = oracle.discretize(D, 0.0, 1.0)
-        it, deff, conv, _, _, _ = oracle.jacobi(A, b, oracle.linear_guess(96, 64, 0.0, 1.0), D, 0.0, 1.0, 1e-4, 200000)
+        it, deff, conv, xk, _, _ = oracle.jacobi(A, b, oracle.linear_guess(96, 64, 0.0, 1.0), D, 0.0, 1.0, 1e-4, 200000)
+        rk = oracle.residual(xk, D, 0.0, 1.0)
         for bs in (3, 1, 2):
             res = results[bs][k]
             assert res["image"] == f"{k:05d}.jpg"
             assert (res["iterations"], res["Deff"], res["converge"]) == (it, deff, conv), (bs, k)
+            assert abs(res["residual"] - rk) <= 1e-12 * rk, (bs, k)      # per slot of a stream (deff_residual_slot)
             assert res["PathFlag"] == int(oracle.floodfill((pixs[k] > 150).astype(np.uint32))[1])
 
 
@@ -534,5 +539,10 @@ def test_driver_3phase_batch_groups(built, tmp_path, oracle):
             assert res["stage_iterations"] == want["stage_sweeps"], (bs, k)
             assert res["Deff"] == want["deff"] and res["converge"] == want["conv"]
             assert res["SVF"] == want["SVF"] and res["LVF"] == want["LVF"] and res["PathFlag"] == int(want["path"])
+            if np.isfinite(want["field"]).all():               # 3 pixel classes, Ds = 0: stacks (deff_residual) and single images
+                rk = oracle.residual(want["field"], oracle.fill_D_3phase(pixs[k], 1.0, 0.0, 2500.0), 0.0, 1.0)
+                assert abs(res["residual"] - rk) <= 1e-12 * rk, (bs, k)
+            else:
+                assert res["residual"] is None
     rows = open(tmp_path / "out.csv").read().splitlines()
     assert rows[0] == "imgNum,SVF,LVF,PathFlag,Deff,Time,nElements,converge,ds,df,dg" and rows[1].startswith("0,")
