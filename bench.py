@@ -94,7 +94,7 @@ def live_traffic(n, kernel, kernel_used):
     return got["FETCH_SIZE"] * 2.0 + got["WRITE_SIZE"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child runs of this command (x2 read correction, gfx950)"
 
 
-def live_kernel_stats(n, kernel, kernel_used, steps, warmup, sweeps_per_step, omega):
+def live_kernel_stats(n, kernel, kernel_used, steps, warmup, sweeps_per_step, omega, keep_as="bench_live_kernel_stats.csv"):
     """Average duration of the dominant sweep kernel as rocprofv3 sees it, measured NOW on this box: one child run of this
     script's timed region (`--primary-only`, same --steps / --warmup / --sweeps-per-step) under `rocprofv3 --kernel-trace
     --stats` (the program itself after `--`).  The summary it parses is also left in gpurun_out/ (copied to profiles/ per
@@ -126,7 +126,7 @@ def live_kernel_stats(n, kernel, kernel_used, steps, warmup, sweeps_per_step, om
             top = max(rows, key=lambda row: float(row["TotalDurationNs"]))
             keep = os.path.join(ROOT, "gpurun_out")
             if os.path.isdir(keep) and os.access(keep, os.W_OK):
-                shutil.copyfile(f, os.path.join(keep, "bench_live_kernel_stats.csv"))
+                shutil.copyfile(f, os.path.join(keep, keep_as))
             child = None
             for line in r.stdout.splitlines():
                 if line.startswith("{") and '"metric"' in line:
@@ -136,7 +136,7 @@ def live_kernel_stats(n, kernel, kernel_used, steps, warmup, sweeps_per_step, om
                     "rocprof_kernel": top["Name"].split("(")[0],
                     "rocprof_child_launch_us": child["roofline"]["launch_us"] if child else None,
                     "rocprof_source": "rocprofv3 --kernel-trace --stats, one child run of this command's timed region "
-                                      "(--primary-only) on this box; summary kept as gpurun_out/bench_live_kernel_stats.csv"}
+                                      f"(--primary-only) on this box; summary kept as gpurun_out/{keep_as}"}
         except Exception:
             return None
 
@@ -158,10 +158,10 @@ def iters_to_tol_1024(pkg, device, kernel):
                           "stopping rule, tol 1e-6, check every 10 000 sweeps, wall time of deff_solve() incl. all checks"}
 
 
-def cpu_baseline(n, seconds_target=12.0):
+def cpu_baseline(n, seconds_target=12.0, fixed_sweeps=None):
     """Single-thread oracle sweep rate on the same synthetic workload (bounded sample).
     Returns (block, sweeps, field): the field after `sweeps` sweeps from the linear guess is kept so that
-    the GPU path can be checked against it (parity_checked)."""
+    the GPU path can be checked against it (parity_checked).  fixed_sweeps: SURVEY.md 8d's counts for the small configs."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     ob.build()
@@ -172,7 +172,7 @@ def cpu_baseline(n, seconds_target=12.0):
     t0 = time.perf_counter()
     x = ob.sweeps(A, b, x, 2)
     per = (time.perf_counter() - t0) / 2
-    k = max(2, min(2000, int(seconds_target / max(per, 1e-9))))
+    k = fixed_sweeps or max(2, min(2000, int(seconds_target / max(per, 1e-9))))
     t0 = time.perf_counter()
     x = ob.sweeps(A, b, x, k)
     dt = time.perf_counter() - t0
@@ -476,6 +476,18 @@ def main():
     if rank == 0 and world == 1 and args.batch == 1 and not args.no_iters_to_tol:
         tol1024 = iters_to_tol_1024(pkg, local_rank, args.kernel)
 
+    # Residual() of the reference (cuh:451-494) as a wave-level reduction over the field (kernels_residual.hpp): device time of
+    # one evaluation and its HBM fraction against the algorithmic 9 B per cell (x 8 + pixel 1; no D plane is read)
+    resid = None
+    if rank == 0 and args.batch == 1 and not args.primary_only:
+        t = sorted(s.residual(timing=True)[1] for _ in range(12))
+        rbytes = 9.0 * float(n) * n
+        resid = {"value": s.residual(), "device_us": t[0] * 1e3, "median_us": t[len(t) // 2] * 1e3,
+                 "algorithmic_bytes": rbytes, "achieved_GBs": rbytes / (t[0] * 1e-3) / 1e9,
+                 "frac_of_hbm_peak": rbytes / (t[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "sample": "deff_residual() on the field the timed steps left: k_residual_classes + k_residual_final, HIP events, "
+                           "best / median of 12; 9 B per cell (x 8 + pixel 1)"}
+
     if rank == 0:
         cells = float(n) * n * args.batch
         total_launches = args.steps * launches
@@ -550,6 +562,14 @@ def main():
             tre = traffic_of(ek)
             if tre:
                 roofline["contract_64B_traffic"] = tre["hbm_bytes_per_launch"]
+            if world == 1 and args.batch == 1 and not args.no_live_stats:
+                # the same figure from rocprofv3 on this box: one child run on the explicit kernel (3 x 300 sweeps)
+                ste = live_kernel_stats(n, "explicit", "explicit", 2, 1, 300, args.omega, keep_as="bench_live_explicit_kernel_stats.csv")
+                if ste:
+                    roofline["contract_64B_rocprof_avg_us"] = ste["rocprof_avg_us"]
+                    roofline["contract_64B_rocprof_min_us"] = ste["rocprof_min_us"]
+                    roofline["contract_64B_rocprof_calls"] = ste["rocprof_calls"]
+                    roofline["contract_64B_rocprof_frac"] = BYTES_PER_CELL_SWEEP * cells / (ste["rocprof_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
 
         out = {
             "metric": "Mcells*iter/s (Jacobi sweep) at 4096^2" if n == 4096 else f"Mcells*iter/s (Jacobi sweep) at {n}^2",
@@ -600,9 +620,21 @@ def main():
                                         "sample": "2400 sweeps (best of 3) of ONE 2048x2048 synthetic image, same physics, one GPU"}
         if tol1024:
             out["iters_to_tol_1024"] = tol1024
+        if resid:
+            out["residual_4096" if n == 4096 else f"residual_{n}"] = resid
+        if n == 4096 and not args.primary_only:
+            # BASELINE.json's metric names iterations-to-tolerance AT 4096^2: 664 s of solving cannot sit inside a bench run
+            # that has to finish in minutes, so the figure is CITED from the builder's own run, not timed by the driver
+            out["iters_to_tol_4096"] = {"iters": 47200001, "seconds": 664, "deff": 0.006838670769926945, "tol": 1e-6,
+                                        "source": "profiles/r03_iterations_to_tolerance_4096.log (tools/measure_tol_4096.py)",
+                                        "measured_by": "builder, round 3; same count and Deff in rounds 1 and 2 -- NOT timed in this run"}
         if world == 1 and not args.no_cpu_baseline:
             base, K, want = cpu_baseline(n)
             out["cpu_baseline"] = base
+            if not args.primary_only:
+                # the same single-thread oracle at configs #1 / #2's sizes (2 000 / 50 sweeps)
+                out["cpu_baseline_128"] = cpu_baseline(128, fixed_sweeps=2000)[0]
+                out["cpu_baseline_1024"] = cpu_baseline(1024, fixed_sweeps=50)[0]
             if args.batch != 1:
                 print(json.dumps(out), flush=True)
                 s.close()
