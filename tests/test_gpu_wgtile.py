@@ -385,6 +385,33 @@ def test_resident_passes_with_a_second_context_loading_the_gpu(pkg):
     assert got == [ref] * 3
 
 
+@pytest.mark.parametrize("n,want_nw", [(1024, 12), (640, 8), (1536, 16), (2048, 16)])
+def test_long_solve_resident_equals_one_launch_per_pass(pkg, n, want_nw):
+    """short parity tests do not catch exchange races (round 3's mailbox variant passed all of them and got
+    one 150 001-sweep solve wrong), so the suite itself holds long ones: 150 001 sweeps through the solve loop (16 checks,
+    ~18 750 flag-synchronised passes per tile) on each resident form -- 12-wave link-symmetric tiles (1024^2), 8-wave tiles
+    (640^2), tall 16-wave tiles (1536^2, 2048^2) -- must give the SHA-256 of the field, the Deff and the last change of one
+    launch per pass."""
+    import hashlib
+
+    def solve(launch):
+        with pkg.Solver(n, n, kernel="matfree_tb") as s:
+            s.set_tuning("tb_launch", launch)
+            s.synth_image(12345, 0)
+            s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            s.init_linear(0.0, 1.0)
+            r = s.solve(1e-30, 150001)
+            p = s.plan()
+            assert p["tb_resident"] == (0 if launch == 1 else 1) and s.plan_value("tb_fallbacks") == 0
+            if launch == 0:
+                assert p["tb_NW"] == want_nw, p
+            return r.iters, r.checks, r.deff_raw, r.conv, hashlib.sha256(s.get_field().tobytes()).hexdigest()
+
+    a, b = solve(0), solve(1)
+    assert a[0] == 150001 and a[1] == 16
+    assert a == b
+
+
 # ---- tall resident tiles: 16 waves x R rows, field in registers, codes in LDS, matrix rows looked up in every sweep ----
 
 TALL_SHAPES = [(300, 200), (1030, 137), (600, 700), (250, 333), (2, 164), (97, 241), (1281, 410), (122, 9)]
