@@ -106,7 +106,7 @@ def test_residual_2phase_vs_oracle(pkg, oracle, nx, ny):
             want = oracle.residual(x, D, CL, CR)
             got = s.residual()
             assert close(got, want), (sweeps, got, want)
-            assert s.residual() == got                                   # deterministic
+            assert all(s.residual() == got for _ in range(20))           # deterministic: whichever workgroup finishes last
             assert close(s.residual(D, CL, CR), want)
         # any field, not only iterates
         f = rng.random((ny, nx)) * 3 - 1
