@@ -108,6 +108,8 @@ try {
         }
     } while (0);
     if (rc != DEFF_OK) return rc;
+    resident_chain_ctx_created(device);
+    c->chain_counted = true;
     guard.c = nullptr;
     *out = c;
     return DEFF_OK;
@@ -129,6 +131,7 @@ try {
     if (c->res_abort) (void)hipFree(c->res_abort);
     if (c->res_backup) (void)hipFree(c->res_backup);
     if (c->q_host) (void)hipHostFree(c->q_host);
+    if (c->chain_counted) resident_chain_ctx_destroyed(c->device);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);

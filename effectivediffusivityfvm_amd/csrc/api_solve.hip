@@ -210,6 +210,24 @@ static int wgr_resident_blocks(const deff_ctx *c, int T, int R, bool fma, bool g
 static std::mutex g_res_mu;
 static hipEvent_t g_res_ev[64];
 static bool g_res_has[64];
+static int g_res_users[64];          // contexts alive per device: the chain's event goes with the last of them
+
+void resident_chain_ctx_created(int device)
+{
+    if (device < 0 || device >= 64) return;
+    std::lock_guard<std::mutex> lock(g_res_mu);
+    ++g_res_users[device];
+}
+
+// (called by deff_destroy with the device current and the context's stream drained)
+void resident_chain_ctx_destroyed(int device)
+{
+    if (device < 0 || device >= 64) return;
+    std::lock_guard<std::mutex> lock(g_res_mu);
+    if (--g_res_users[device] > 0 || !g_res_has[device]) return;
+    (void)hipEventDestroy(g_res_ev[device]);     // nobody is left to wait on it; the next context of this device starts a new chain
+    g_res_has[device] = false;
+}
 
 static hipError_t resident_chain_begin(const deff_ctx *c)
 {

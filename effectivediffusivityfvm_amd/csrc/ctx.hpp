@@ -182,6 +182,7 @@ struct deff_ctx {
     int64_t res_redo = 0;
     double res_omega = 0;
     int res_fallbacks = 0;                       // aborted resident intervals redone with one launch per pass
+    bool chain_counted = false;                  // this context is counted among its device's users of the resident chain's event
     int fma = 0;                                 // contracted arithmetic (kernels_sweep.hpp), opt-in
     int tb_xmajor = 1;                           // wave-tile numbering of the temporally blocked kernel
     int64_t last_launches = 0;                   // sweep-kernel launches of the last deff_sweeps()/deff_solve()
@@ -316,4 +317,6 @@ int enqueue_sweeps(deff_ctx *c, const SweepPlan &pl, int64_t n);   // stops at t
 // did a resident launch give up waiting?  (synchronises if one is pending; on an abort the interval is redone with one
 // launch per pass and the context stays in that mode)
 int resident_check(deff_ctx *c);
+void resident_chain_ctx_created(int device);
+void resident_chain_ctx_destroyed(int device);
 int flux_rows(deff_ctx *c, bool need_rows = true);
