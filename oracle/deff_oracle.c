@@ -282,12 +282,18 @@ double oracle_flux_deff(const double *x, const double *D, int nx, int ny, double
  *    with H's arguments in the order (D[row+-1], D[row]); top row qN = 0, bottom row qS = 0;
  *  - R += fabs(qW - qE + qN - qS) over rows, then columns, ascending; R / (numCols*numRows).
  * Nothing in /root/reference holds a value of it: parity of the HIP residual is to this restatement only. */
-double oracle_residual(const double *cmap, const double *D, int numRows, int numCols, double TL, double TR)
+/* exact_out (may be NULL): the same per-cell doubles added in long double (x87: 64-bit mantissa) -- NOT the reference's
+ * number, a yardstick: the serial double sum drifts from it by up to ~n * 2^-53 relative (observed 2e-12 at 512^2 on a rough
+ * medium), which is more than a tree sum does, so tests compare a reduction in another order against this one tightly and
+ * against the serial one within the serial sum's own error bound. */
+double oracle_residual_ex(const double *cmap, const double *D, int numRows, int numCols, double TL, double TR,
+                          double *exact_out)
 {
     double dx = 1.0 / numCols;
     double dy = 1.0 / numRows;
     double qE, qW, qS, qN;
     double R = 0;
+    long double Rl = 0;
     for (int row = 0; row < numRows; row++) {
         for (int col = 0; col < numCols; col++) {
             const size_t p = (size_t)row * numCols + col;
@@ -312,10 +318,17 @@ double oracle_residual(const double *cmap, const double *D, int numRows, int num
                 qN = dy / dx * oracle_whm(dx / 2, dx / 2, D[p - numCols], D[p]) * (cmap[p] - cmap[p - numCols]);
             }
             R += fabs(qW - qE + qN - qS);
+            Rl += (long double)fabs(qW - qE + qN - qS);
         }
     }
     R = R / (numCols * numRows);
+    if (exact_out) *exact_out = (double)(Rl / (long double)(numCols * numRows));
     return R;
+}
+
+double oracle_residual(const double *cmap, const double *D, int numRows, int numCols, double TL, double TR)
+{
+    return oracle_residual_ex(cmap, D, numRows, numCols, TL, TR, 0);
 }
 
 /* cuh:1163-1314 JacobiGPU (and cuh:1024-1160 JacobiGPUPreCond, which runs the

@@ -68,6 +68,8 @@ def lib(flavour=None):
     L.oracle_jacobi.restype = C.c_long
     L.oracle_residual.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double]
     L.oracle_residual.restype = C.c_double
+    L.oracle_residual_ex.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    L.oracle_residual_ex.restype = C.c_double
     L.oracle_floodfill.argtypes = [_u32p, C.c_int, C.c_int]
     L.oracle_floodfill.restype = C.c_int
     L.oracle_fracts_3d.argtypes = [_dp, C.c_long, C.c_double, C.c_double, C.POINTER(C.c_double),
@@ -166,6 +168,28 @@ def residual(x, D, CL, CR, flavour=None):
     ny, nx = x.shape
     assert D.shape == x.shape
     return float(lib(flavour).oracle_residual(x, D, ny, nx, CL, CR))
+
+
+def residual_exact(x, D, CL, CR):
+    """(serial, exact): Residual() in the reference's order, and the same per-cell doubles added in long double (a yardstick
+    for reductions in another order; see oracle_residual_ex)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    D = np.ascontiguousarray(D, dtype=np.float64)
+    ny, nx = x.shape
+    ex = C.c_double()
+    r = lib().oracle_residual_ex(x, D, ny, nx, CL, CR, C.byref(ex))
+    return float(r), ex.value
+
+
+def assert_residual(got, x, D, CL, CR):
+    """A residual reduced in another order than the reference's serial sum: within 1e-13 of the exactly added per-cell terms
+    (tree sums lose ~log2(n) ulps), and within the serial sum's own error bound (n * 2^-53, at least 1e-12) of the oracle."""
+    serial, exact = residual_exact(x, D, CL, CR)
+    if not np.isfinite(serial):
+        assert not np.isfinite(got)
+        return
+    assert abs(got - exact) <= 1e-13 * exact, (got, exact, serial)
+    assert abs(got - serial) <= max(1e-12, x.size * 2.0 ** -53) * serial, (got, serial)
 
 
 def floodfill(grid):

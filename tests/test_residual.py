@@ -7,12 +7,13 @@ solution of a uniform medium has residual ~0; (ii) on a square mesh (dx = dy) a 
 rounding, (A x - b) of the reference's own assembly, so mean|A x - b| must agree to ~1e-12 -- an evaluation that shares no
 code with oracle_residual; (iii) a vectorised numpy restatement of the same expressions.
 
-Bar for the HIP path: every cell's term follows the reference's arithmetic; only the order of the sum differs (wave-level tree
-instead of serial row-major), so 1e-12 relative (observed ~1e-15), and bit-identical from run to run."""
+Bar for the HIP path (oracle_binding.assert_residual): every cell's term follows the reference's arithmetic and only the order
+of the sum differs (wave-level tree instead of serial row-major).  The serial double sum is the LESS accurate of the two -- it
+drifts from the exactly added terms by up to n * 2^-53 (observed 2e-12 at 512^2 on a rough medium) -- so the comparison is
+(a) within 1e-13 of the oracle's per-cell doubles added in long double, which is what shows that the CELLS are right, and
+(b) within max(1e-12, n * 2^-53) of the oracle's serial sum; plus bit-identical from call to call."""
 import numpy as np
 import pytest
-
-TOL = 1e-12
 
 
 def numpy_residual(x, D, CL, CR):
@@ -80,8 +81,6 @@ def pkg():
     return p
 
 
-def close(a, b):
-    return abs(a - b) <= TOL * abs(b)
 
 
 @pytest.mark.gpu
@@ -103,15 +102,14 @@ def test_residual_2phase_vs_oracle(pkg, oracle, nx, ny):
             if sweeps:
                 s.sweeps(sweeps)
                 x = oracle.sweeps(A, b, x, sweeps)
-            want = oracle.residual(x, D, CL, CR)
             got = s.residual()
-            assert close(got, want), (sweeps, got, want)
-            assert all(s.residual() == got for _ in range(20))           # deterministic: whichever workgroup finishes last
-            assert close(s.residual(D, CL, CR), want)
+            oracle.assert_residual(got, x, D, CL, CR)
+            assert all(s.residual() == got for _ in range(20))           # deterministic
+            oracle.assert_residual(s.residual(D, CL, CR), x, D, CL, CR)
         # any field, not only iterates
         f = rng.random((ny, nx)) * 3 - 1
         s.set_field(f)
-        assert close(s.residual(), oracle.residual(f, D, CL, CR))
+        oracle.assert_residual(s.residual(), f, D, CL, CR)
 
 
 @pytest.mark.gpu
@@ -129,7 +127,7 @@ def test_residual_with_mesh_amplification(pkg, oracle, ampX, ampY):
         s.assemble_2phase(1e-2, 2.0, 0.0, 1.0)
         s.init_linear(0.0, 1.0)
         s.sweeps(9)
-        assert close(s.residual(), oracle.residual(x, D, 0.0, 1.0))
+        oracle.assert_residual(s.residual(), x, D, 0.0, 1.0)
 
 
 @pytest.mark.gpu
@@ -146,7 +144,8 @@ def test_residual_img00000_converged_field(pkg, oracle, img00000):
         s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
         s.set_field(x)
         got = s.residual()
-    assert close(got, want) and 0 < want < 1e-6
+    oracle.assert_residual(got, x, D, 0.0, 1.0)
+    assert 0 < want < 1e-6
 
 
 @pytest.mark.gpu
@@ -167,9 +166,9 @@ def test_residual_3phase_with_impermeable_solid(pkg, oracle):
         s.init_linear(0.0, 1.0)
         s.sweeps(40)
         assert np.isfinite(x).all() and np.array_equal(s.get_field(), x)
-        want = oracle.residual(x, D, 0.0, 1.0)
-        assert np.isfinite(want) and close(s.residual(), want)
-        assert close(s.residual(D, 0.0, 1.0), want)
+        assert np.isfinite(oracle.residual(x, D, 0.0, 1.0))
+        oracle.assert_residual(s.residual(), x, D, 0.0, 1.0)
+        oracle.assert_residual(s.residual(D, 0.0, 1.0), x, D, 0.0, 1.0)
 
 
 @pytest.mark.gpu
@@ -186,7 +185,7 @@ def test_residual_of_a_stack_is_per_image(pkg, oracle):
     assert got.shape == (B,)
     for k in range(B):
         D = oracle.fill_D_2phase(pix[k], 1.0, 1e-3)
-        assert close(got[k], oracle.residual(f[k * ny:(k + 1) * ny], D, 0.0, 1.0))
+        oracle.assert_residual(got[k], f[k * ny:(k + 1) * ny], D, 0.0, 1.0)
 
 
 @pytest.mark.gpu
@@ -208,7 +207,7 @@ def test_residual_from_the_progress_callback_and_after_assemble_from_D(pkg, orac
     for k, got in seen:
         x = oracle.sweeps(A, b, x, k + 1 - done)
         done = k + 1
-        assert close(got, oracle.residual(x, D, 0.0, 1.0))
+        oracle.assert_residual(got, x, D, 0.0, 1.0)
     assert seen[0][1] > seen[1][1] > seen[2][1]
     # a system assembled from a D plane carries no pixel classes: deff_residual says so, deff_residual_D works
     with pkg.Solver(nx, ny) as s:
@@ -216,4 +215,4 @@ def test_residual_from_the_progress_callback_and_after_assemble_from_D(pkg, orac
         s.init_linear(0.0, 1.0)
         with pytest.raises(pkg.DeffError, match="deff_residual_D"):
             s.residual()
-        assert close(s.residual(D, 0.0, 1.0), oracle.residual(oracle.linear_guess(nx, ny, 0.0, 1.0), D, 0.0, 1.0))
+        oracle.assert_residual(s.residual(D, 0.0, 1.0), oracle.linear_guess(nx, ny, 0.0, 1.0), D, 0.0, 1.0)
