@@ -227,15 +227,18 @@ def bench_slab_one_gpu(args, pkg, torch, local_rank):
         "Mcells_iter_per_s": {k: cells * S / v / 1e6 for k, v in out.items()}}), flush=True)
 
 
-def bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier, use_dist):
+def bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier, use_dist, gather_elapsed):
     """One --size x --size image split into `world` row slabs (RCCL halo exchange per blocked pass)."""
     if world == 1 and args.slabs > 1:
         return bench_slab_one_gpu(args, pkg, torch, local_rank)
     n, S = args.size, args.sweeps_per_step
-    uid = [pkg.rccl_unique_id() if rank == 0 else None]
-    if use_dist:
-        dist.broadcast_object_list(uid, src=0)
-    s = pkg.SlabRank(n, n, rank, world, uid[0], device=local_rank)
+    if args.transport == "host" and use_dist:
+        s = pkg.SlabRank(n, n, rank, world, None, device=local_rank, transport=pkg.TorchDistTransport())
+    else:
+        uid = [pkg.rccl_unique_id() if rank == 0 else None]
+        if use_dist:
+            dist.broadcast_object_list(uid, src=0)
+        s = pkg.SlabRank(n, n, rank, world, uid[0], device=local_rank)
     for kv in args.tune:
         k, v = kv.split("=")
         s.set_tuning(k, int(v))
@@ -254,11 +257,9 @@ def bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier, use_dis
     elapsed = time.perf_counter() - t0
     per_rank_ms = [elapsed / args.steps * 1e3]
     if use_dist:
-        mine = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
-        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
-        elapsed = max(float(t.item()) for t in every)
+        every = gather_elapsed(elapsed)
+        per_rank_ms = [t / args.steps * 1e3 for t in every]
+        elapsed = max(every)
     if rank == 0:
         cells = float(n) * n
         print(json.dumps({
@@ -268,10 +269,12 @@ def bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier, use_dis
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"ONE {n}x{n} synthetic two-phase image split into {world} row slabs, 8-row halos, "
-                                   f"RCCL send/recv once per temporally blocked pass; step = {S} sweeps",
-                       "kernel": "matfree_tb", "sweeps_per_step": S}}), flush=True)
+                                   f"{'host-staged (gloo)' if args.transport == 'host' else 'RCCL'} send/recv once per temporally blocked pass; step = {S} sweeps"
+                                   + ("; REHEARSAL: the ranks share GPUs" if args.share_gpu else ""),
+                       "kernel": "matfree_tb", "sweeps_per_step": S, "transport": args.transport}}), flush=True)
     s.close()
     if use_dist:
+        barrier()
         dist.destroy_process_group()
 
 
@@ -343,6 +346,14 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per GPU swept together (dataset-generation mode)")
     ap.add_argument("--slabs", type=int, default=1, help="--mode slab on ONE GPU: split the image into this many slabs "
                                                          "(one process, peer copies) and report the exchange's exposed time")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+                    help="N > 1: rccl = torch.distributed 'nccl' backend (RCCL over xGMI; the slabs' halo exchange is grouped "
+                         "ncclSend/ncclRecv) -- the product path; host = gloo + host-staged halo blocks (TorchDistTransport): "
+                         "for rehearsals on boxes where RCCL cannot connect the ranks")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: rank r uses device r mod (GPUs present); needs "
+                         "--transport host (RCCL refuses two ranks on one device); the ranks then SHARE a GPU, so the line's "
+                         "value says nothing about scaling")
     ap.add_argument("--launch-dry", action="store_true", help="start the ranks, join a gloo group, report rank/world and "
                                                               "exit: the launcher's test (no GPU needed)")
     args = ap.parse_args()
@@ -365,6 +376,10 @@ def main():
     import torch.distributed as dist
 
     ndev = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if args.share_gpu and world > 1 and args.transport != "host":
+        sys.exit("bench.py: --share-gpu needs --transport host (RCCL refuses two ranks on one device)")
+    if args.share_gpu and ndev > 0:
+        local_rank = local_rank % ndev        # rehearsal: the ranks share the GPUs that are there
     if local_rank >= ndev:
         sys.exit(f"bench.py rank {rank}: device {local_rank} of {ndev} (this box has fewer GPUs than --gpus {world}; "
                  "there is no CPU fallback)")
@@ -375,16 +390,36 @@ def main():
     torch.cuda.set_device(local_rank)
     # under torch.distributed.run (any N, also N = 1) use the process group: RCCL over xGMI
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    host_transport = args.transport == "host"
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if host_transport:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if use_dist:
-            dist.barrier(device_ids=[local_rank])
+            if host_transport:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
 
+    def gather_elapsed(elapsed):
+        """every rank's own time (a slow rank must be visible in the line); max = all_reduce(MAX)"""
+        mine = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_transport else "cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        return [float(t.item()) for t in every]
+
+    # N > 1: the scaling line needs the timed steps only; the secondary legs (explicit kernel, omega = 1, contracted arithmetic,
+    # small images, residual, CPU baseline) are rank 0's business at N = 1 and would only keep the other ranks waiting
+    lean = args.primary_only or world > 1
+    if world > 1:
+        args.explicit_sweeps = 0
+        args.no_small_image = args.no_iters_to_tol = args.no_cpu_baseline = True
     n, S = args.size, args.sweeps_per_step
     if args.mode == "slab":
-        return bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier, use_dist)
+        return bench_slab(args, pkg, torch, dist, world, rank, local_rank, barrier, use_dist, gather_elapsed)
     s = pkg.Solver(n, n, device=local_rank, kernel=args.kernel, nimg=args.batch)
     for kv in args.tune:
         k, v = kv.split("=")
@@ -413,11 +448,9 @@ def main():
     elapsed = time.perf_counter() - t0
     per_rank_ms = [elapsed / args.steps * 1e3]
     if use_dist:
-        mine = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)                      # per-rank times: a slow rank must be visible in the line
-        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
-        elapsed = max(float(t.item()) for t in every)     # = all_reduce(MAX)
+        every = gather_elapsed(elapsed)
+        per_rank_ms = [t / args.steps * 1e3 for t in every]
+        elapsed = max(every)
 
     launches, sweeps_per_launch = s.last_launches()     # of the last step
     kernel_used = s.kernel_in_use()
@@ -435,7 +468,7 @@ def main():
 
     # second reported row: plain Jacobi, omega = 1 (updateX_V1's arithmetic), same kernel
     omega1_ms = None
-    if abs(args.omega - 1.0) > 1e-12 and not args.primary_only:
+    if abs(args.omega - 1.0) > 1e-12 and not lean:
         s.sweeps(sweeps_per_launch * 4, 1.0)
         omega1_ms = s.sweeps(S, 1.0)
 
@@ -443,7 +476,7 @@ def main():
     # into adds as a compiler contracts the reference's expression; bit-identical to the oracle's fma
     # build, NOT to the default arithmetic -- reported beside `value`, never as `value`)
     fma_ms = None
-    if kernel_used != "explicit" and not args.primary_only:
+    if kernel_used != "explicit" and not lean:
         s.set_tuning("fma", 1)
         s.sweeps(sweeps_per_launch * 4, args.omega)
         fma_ms = s.sweeps(S, args.omega)
@@ -479,7 +512,7 @@ def main():
     # Residual() of the reference (cuh:451-494) as a wave-level reduction over the field (kernels_residual.hpp): device time of
     # one evaluation and its HBM fraction against the algorithmic 9 B per cell (x 8 + pixel 1; no D plane is read)
     resid = None
-    if rank == 0 and args.batch == 1 and not args.primary_only:
+    if rank == 0 and args.batch == 1 and not lean:
         t = sorted(s.residual(timing=True)[1] for _ in range(12))
         rbytes = 9.0 * float(n) * n
         resid = {"value": s.residual(), "device_us": t[0] * 1e3, "median_us": t[len(t) // 2] * 1e3,
@@ -587,7 +620,8 @@ def main():
             "config": {
                 "workload": f"{n}x{n} synthetic two-phase image (splitmix64 seed 12345, porosity 0.5), Ds=1e-3 Df=1 "
                             f"CL=0 CR=1, omega={args.omega:.6g}; step = {S} sweeps + 1 Deff evaluation; "
-                            f"{args.batch} image(s) per GPU (image index = rank), no inter-GPU communication",
+                            f"{args.batch} image(s) per GPU (image index = rank), no inter-GPU communication"
+                            + ("; REHEARSAL: the ranks share GPUs (--share-gpu)" if args.share_gpu and world > 1 else ""),
                 "kernel": kernel_used,
                 "sweeps_per_step": S,
                 "sweeps_per_launch": sweeps_per_launch,
@@ -622,7 +656,7 @@ def main():
             out["iters_to_tol_1024"] = tol1024
         if resid:
             out["residual_4096" if n == 4096 else f"residual_{n}"] = resid
-        if n == 4096 and not args.primary_only:
+        if n == 4096 and not lean:
             # BASELINE.json's metric names iterations-to-tolerance AT 4096^2: 664 s of solving cannot sit inside a bench run
             # that has to finish in minutes, so the figure is CITED from the builder's own run, not timed by the driver
             out["iters_to_tol_4096"] = {"iters": 47200001, "seconds": 664, "deff": 0.006838670769926945, "tol": 1e-6,
@@ -657,6 +691,7 @@ def main():
             print(json.dumps(out), flush=True)
     s.close()
     if use_dist:
+        barrier()                                  # every rank leaves together
         dist.destroy_process_group()
 
 

@@ -6,5 +6,5 @@ Importing it never touches the GPU; creating a Solver does and fails loudly if
 the library or a device is missing.
 """
 from ._capi import DeffError, KERNEL_NAMES, LIB_PATH  # noqa: F401
-from .solver import (OMEGA_REFERENCE, SlabGroup, SlabRank, Solver, SolveResult, flood_fill, recommended_batch,  # noqa: F401
-                     load_jpeg_gray, rccl_unique_id)
+from .solver import (OMEGA_REFERENCE, SlabGroup, SlabRank, Solver, SolveResult, TorchDistTransport, flood_fill,  # noqa: F401
+                     recommended_batch, load_jpeg_gray, rccl_unique_id)

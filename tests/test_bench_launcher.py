@@ -72,3 +72,29 @@ def test_too_few_gpus_is_reported_by_the_ranks():
     assert r.returncode != 0
     assert f"rank 1: device 1 of {ndev}" in r.stderr, r.stderr
     assert "must be launched with" not in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,n", [("images", 2), ("slab", 3)])
+def test_rehearsal_of_n_ranks_sharing_one_gpu(mode, n):
+    """The N > 1 paths of bench.py on hardware, as far as a one-GPU box allows: `python bench.py --gpus N --share-gpu --transport
+    host` -- self-launched ranks, each with its own context (images) or its slab of one image (slab), barrier, max-over-ranks
+    timing, one JSON line from rank 0 -- with the ranks sharing the GPU and gloo / host-staged halo blocks in place of RCCL
+    (which refuses two ranks on one device).  What stays unexecuted is the RCCL transport itself."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--share-gpu", "--transport", "host", "--mode", mode, "--size", "1024",
+                        "--steps", "2", "--warmup", "1", "--sweeps-per-step", "64"], env=_env(), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == n and len(out["per_rank_ms_per_step"]) == n and out["steps"] == 2
+    assert "REHEARSAL" in out["config"]["workload"]
+    cells = 1024.0 * 1024.0 * (n if mode == "images" else 1)
+    assert abs(out["value"] - cells * 64 / (out["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * out["value"]
+    assert out["scaling"] == ("weak" if mode == "images" else "strong")
+
+
+@pytest.mark.gpu
+def test_share_gpu_with_rccl_is_refused_by_the_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--share-gpu", "--steps", "1"], env=_env(), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode != 0 and "--share-gpu needs --transport host" in r.stderr
