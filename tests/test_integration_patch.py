@@ -8,10 +8,13 @@ readInputFile, FloodFill, Residual, the CSV writers and main, unchanged, on the 
 reference_seam.hpp and the reference's call sites breaks this test instead of a reader.  Nothing of the reference is
 committed or travels: the copy lives in pytest's tmp_path.
 
-Cross-check riding along (it pins nothing by the pipeline's rules -- the build only exists through the patch, and
-WeightedHarmonicMean inside it is the seam's): the patched translation unit still holds the reference's own text of
-Residual() (cuh:451-494), a host function; a 12-line probe of ours calls it on a small case and the oracle's restatement
-must return the same double, bit for bit (same serial order)."""
+Cross-checks riding along (they pin nothing by the pipeline's rules -- the build only exists through the patch, and
+WeightedHarmonicMean inside it is the seam's): the patched translation unit still holds the reference's own text of its
+host-only functions.  Small probes of ours call them: Residual() (cuh:451-494) -- the oracle's restatement must return the
+same double, bit for bit (same serial order); FloodFill() (cuh:557-713), calcPorosity() (cuh:383-408) and calcFracts3D()
+(cuh:411-448) -- the oracle's and the library's flood fill must mark the same cells (including the right-column seeding
+quirk of cuh:601, with and without a solid top-left cell, and the top <-> bottom wrap) and the volume fractions must be
+the same doubles."""
 import os
 import subprocess
 
@@ -103,3 +106,68 @@ def test_reference_residual_text_agrees_with_the_oracle(tmp_path, oracle):
         r = subprocess.run([str(tmp_path / "probe"), "case.bin"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
         assert r.returncode == 0, r.stderr
         assert float(r.stdout) == oracle.residual(x, D, CL, CR), (nx, ny)
+
+
+PROBE_FILL = r"""
+#include "Deff2D.cuh"
+// in: nx ny | ny*nx uint8 pixels | threshold.  out (text): porosity, SVF, LVF, then the flood-filled Grid, one digit per cell
+int main(int argc, char **argv) {
+    FILE *f = fopen(argv[1], "rb");
+    int dims[3];
+    if (!f || fread(dims, sizeof(int), 3, f) != 3) return 2;
+    const int nx = dims[0], ny = dims[1], thr = dims[2];
+    std::vector<unsigned char> pix((size_t)nx * ny);
+    if (fread(pix.data(), 1, pix.size(), f) != pix.size()) return 2;
+    meshInfo mesh; mesh.numCellsX = nx; mesh.numCellsY = ny; mesh.nElements = nx * ny; mesh.dx = 1.0 / nx; mesh.dy = 1.0 / ny;
+    simulationInfo info; memset(&info, 0, sizeof info);
+    options o; memset(&o, 0, sizeof o); o.DCsolid = 0.5; o.DCfluid = 1.0; o.DCgas = 30.0;
+    std::vector<unsigned int> Grid((size_t)nx * ny);
+    std::vector<double> D((size_t)nx * ny);
+    for (size_t p = 0; p < Grid.size(); ++p) {
+        Grid[p] = pix[p] > thr ? 1 : 0;
+        D[p] = pix[p] > 200 ? o.DCsolid : (pix[p] < 50 ? o.DCgas : o.DCfluid);      // cuh:1518-1529
+    }
+    FloodFill(Grid.data(), &mesh, &info);
+    calcFracts3D(&info, D.data(), &mesh, &o);
+    printf("%.17g %.17g %.17g\n", calcPorosity(pix.data(), nx, ny), info.SVF, info.LVF);
+    for (size_t p = 0; p < Grid.size(); ++p) putchar('0' + (int)Grid[p]);
+    putchar('\n');
+    return 0;
+}
+"""
+
+
+def test_reference_flood_fill_and_fractions_agree_with_ours(tmp_path, oracle):
+    if not os.path.exists(os.path.join(LIBDIR, "libdeff_amd.so")):
+        pytest.skip("libdeff_amd.so not built")
+    import effectivediffusivityfvm_amd as pkg
+    apply_section_A(tmp_path)
+    (tmp_path / "probe_fill.cpp").write_text(PROBE_FILL)
+    r = subprocess.run(["g++", "-O1", "-ffp-contract=off", "-std=c++17", "-w", f"-I{REF}", f"-I{CSRC}", "probe_fill.cpp", "-o", "probe_fill",
+                        f"-L{LIBDIR}", "-ldeff_amd", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-4000:]
+    rng = np.random.default_rng(4)
+    vals = np.array([0, 30, 120, 149, 150, 199, 200, 201, 255], dtype=np.uint8)
+    for case in range(60):
+        nx, ny = int(rng.integers(2, 40)), int(rng.integers(2, 40))
+        pix = rng.choice(vals, size=(ny, nx), p=None)
+        if case % 3 == 0:
+            pix[0, 0] = 255                                  # solid top-left: the right column is seeded (cuh:601)
+        if case % 3 == 1:
+            pix[0, 0] = 0
+        thr = 150 if case % 2 else 200
+        with open(tmp_path / "fill.bin", "wb") as f:
+            f.write(np.array([nx, ny, thr], dtype=np.int32).tobytes() + pix.tobytes())
+        r = subprocess.run([str(tmp_path / "probe_fill"), "fill.bin"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        head, cells = r.stdout.split("\n")[:2]
+        por, svf, lvf = (float(v) for v in head.split())
+        ref_grid = np.frombuffer(cells.encode(), dtype=np.uint8).reshape(ny, nx) - ord("0")
+        g0 = (pix > thr).astype(np.uint32)
+        mine, _ = oracle.floodfill(g0)
+        lib, _ = pkg.flood_fill(g0)
+        assert np.array_equal(ref_grid, mine) and np.array_equal(ref_grid, lib), (case, nx, ny, thr)
+        assert por == oracle.porosity(pix)
+        D = oracle.fill_D_3phase(pix, 1.0, 0.5, 30.0)
+        assert (svf, lvf) == oracle.fracts_3d(D, 0.5, 1.0)
