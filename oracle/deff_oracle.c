@@ -16,9 +16,15 @@
  * each double is produced by the same IEEE-754 operation sequence as a
  * non-contracted build of the reference.
  *
- * Parity pinning: the reference cannot be built in this image (it needs
- * cuda_runtime.h / nvcc launch syntax; no stand-ins are written).  The oracle
- * is pinned against what /root/reference itself holds:
+ * Parity pinning: the reference as a whole cannot be built in this image (it
+ * needs cuda_runtime.h / nvcc launch syntax; no stand-ins are written).  Its
+ * HOST-ONLY functions can: oracle/_ref/ref_host (oracle/Makefile target `ref`,
+ * oracle/ref_host_probe.cpp) is Deff2D.cuh's own text with the CUDA-dependent
+ * lines cut out -- structs, WeightedHarmonicMean, DiscretizeMatrix2D[_ImpSolid],
+ * Residual, FloodFill, calcPorosity, calcFracts3D -- and every function of
+ * this file that restates one of those is pinned to it BIT FOR BIT
+ * (tests/test_ref_host.py).  The sweep kernels and the stopping rule are CUDA
+ * code; for them the oracle is pinned against what /root/reference holds:
  *   (i)   the reference's own stb_image.h, compiled as it lies by
  *         tests/golden/make_stb_fixture.py: the decoded bytes of 00000.jpg are
  *         the pixel fixture every config-#1 golden here is derived from;

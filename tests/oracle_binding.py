@@ -260,3 +260,71 @@ def solve_single_2phase_ramp(pix, DCS, DCF_max, CL, CR, tol, max_iter, ampX=1, a
             break
         count += 1
     return dict(stages=stages, field=x)
+
+
+# ---- oracle/_ref/ref_host: the reference's OWN host-only functions (Deff2D.cuh with the CUDA-dependent lines cut out, see
+# oracle/ref_host_probe.cpp and oracle/Makefile) as a checker.  Built where /root/reference is mounted; the binary travels to
+# the GPU box with the snapshot. ----------------------------------------------------------------------------------------------
+REF_HOST = os.path.join(ORACLE_DIR, "_ref", "ref_host")
+
+
+def have_ref_host():
+    return os.access(REF_HOST, os.X_OK)
+
+
+def _ref_run(args, tmpdir, payload=None, out_bytes=None):
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory(dir=tmpdir) as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        if payload is not None:
+            with open(fin, "wb") as f:
+                f.write(payload)
+        cmd = [REF_HOST] + [a.replace("@in", fin).replace("@out", fout) for a in args]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (cmd, r.stderr)
+        data = open(fout, "rb").read() if out_bytes else None
+        return r.stdout, data
+
+
+def ref_discretize(D, CL, CR, grid=None, tmpdir=None):
+    """The reference's DiscretizeMatrix2D / DiscretizeMatrix2D_ImpSolid (cuh:815-902 / cuh:715-812), its own code."""
+    D = np.ascontiguousarray(D, dtype=np.float64)
+    ny, nx = D.shape
+    payload = np.array([nx, ny, 0 if grid is None else 1], dtype=np.int32).tobytes() + np.array([CL, CR]).tobytes() + D.tobytes()
+    if grid is not None:
+        payload += np.ascontiguousarray(grid, dtype=np.uint32).tobytes()
+    _, data = _ref_run(["assemble", "@in", "@out"], tmpdir, payload, True)
+    a = np.frombuffer(data, dtype=np.float64)
+    n = nx * ny
+    return a[:5 * n].reshape(n, 5).copy(), a[5 * n:].copy()
+
+
+def ref_residual(x, D, CL, CR, tmpdir=None):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    ny, nx = x.shape
+    payload = np.array([nx, ny], dtype=np.int32).tobytes() + np.array([CL, CR]).tobytes() + x.tobytes() + np.ascontiguousarray(D, dtype=np.float64).tobytes()
+    out, _ = _ref_run(["residual", "@in"], tmpdir, payload)
+    return float(out)
+
+
+def ref_floodfill(grid, tmpdir=None):
+    g = np.ascontiguousarray(grid, dtype=np.uint32)
+    ny, nx = g.shape
+    _, data = _ref_run(["floodfill", "@in", "@out"], tmpdir, np.array([nx, ny], dtype=np.int32).tobytes() + g.tobytes(), True)
+    return np.frombuffer(data, dtype=np.uint32).reshape(ny, nx).copy()
+
+
+def ref_fractions(pix, D, DCS, DCF, tmpdir=None):
+    """(porosity, SVF, LVF) by the reference's calcPorosity / calcFracts3D."""
+    pix = np.ascontiguousarray(pix, dtype=np.uint8)
+    ny, nx = pix.shape
+    payload = (np.array([nx, ny], dtype=np.int32).tobytes() + np.array([DCS, DCF]).tobytes() + pix.tobytes()
+               + np.ascontiguousarray(D, dtype=np.float64).tobytes())
+    out, _ = _ref_run(["fractions", "@in"], tmpdir, payload)
+    return tuple(float(v) for v in out.split())
+
+
+def ref_whm(w1, w2, x1, x2):
+    out, _ = _ref_run(["whm", repr(w1), repr(w2), repr(x1), repr(x2)], None)
+    return float(out)
