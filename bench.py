@@ -158,7 +158,7 @@ def iters_to_tol_1024(pkg, device, kernel):
                           "stopping rule, tol 1e-6, check every 10 000 sweeps, wall time of deff_solve() incl. all checks"}
 
 
-def cpu_baseline(n, seconds_target=12.0, fixed_sweeps=None):
+def cpu_baseline(n, seconds_target=12.0, fixed_sweeps=None, with_reference_kernel=False):
     """Single-thread oracle sweep rate on the same synthetic workload (bounded sample).
     Returns (block, sweeps, field): the field after `sweeps` sweeps from the linear guess is kept so that
     the GPU path can be checked against it (parity_checked).  fixed_sweeps: SURVEY.md 8d's counts for the small configs."""
@@ -176,9 +176,26 @@ def cpu_baseline(n, seconds_target=12.0, fixed_sweeps=None):
     t0 = time.perf_counter()
     x = ob.sweeps(A, b, x, k)
     dt = time.perf_counter() - t0
-    return ({"value": n * n * k / dt / 1e6, "unit": "Mcells*iter/s", "cores": 1, "kind": "port",
+    block = {"value": n * n * k / dt / 1e6, "unit": "Mcells*iter/s", "cores": 1, "kind": "port",
              "sample": f"{k} sweeps of the {n}x{n} synthetic image, oracle/deff_oracle.c (gcc -O2, AoS, 1 thread), "
-                       f"host has {os.cpu_count()} logical CPUs"}, k + 2, x)
+                       f"host has {os.cpu_count()} logical CPUs"}
+    if with_reference_kernel and ob.have_ref_kernel():
+        # beside the CPU figure: the REFERENCE's own kernel (Deff2D.cuh:69-118, compiled by hipcc from its own text:
+        # oracle/_ref/ref_kernel) on this GPU, launched as the reference's loop launches it -- one launch, one device
+        # synchronisation and one device-to-device copy per sweep (cuh:1237-1281).  Reported, never compared as `value`;
+        # its field after the same sweeps must be the oracle's bit for bit.
+        try:
+            x0 = ob.linear_guess(n, n, 0.0, 1.0)
+            xr, ms = ob.ref_sweeps(A, b, x0, 40, timing=True, tmpdir="/tmp")
+            same = bool(__import__("numpy").array_equal(xr, ob.sweeps(A, b, x0, 40)))
+            block["reference_kernel_on_this_gpu"] = {
+                "value": n * n * 40 / (ms * 1e-3) / 1e6, "unit": "Mcells*iter/s", "us_per_sweep": ms * 1e3 / 40, "kind": "reference",
+                "bit_identical_to_oracle": same,
+                "sample": "40 sweeps: updateX_SOR as written by the reference, hipcc --offload-arch=gfx950 -O2 -ffp-contract=off, grid "
+                          "n/160+1 x 160, launch + hipDeviceSynchronize + D2D copy per sweep like cuh:1237-1281 (HIP events around the loop)"}
+        except Exception as e:                                        # noqa: BLE001 -- a baseline leg must not fail the bench
+            block["reference_kernel_on_this_gpu"] = {"error": str(e)[:200]}
+    return (block, k + 2, x)
 
 
 def bench_slab_one_gpu(args, pkg, torch, local_rank):
@@ -663,7 +680,7 @@ def main():
                                         "source": "profiles/r03_iterations_to_tolerance_4096.log (tools/measure_tol_4096.py)",
                                         "measured_by": "builder, round 3; same count and Deff in rounds 1 and 2 -- NOT timed in this run"}
         if world == 1 and not args.no_cpu_baseline:
-            base, K, want = cpu_baseline(n)
+            base, K, want = cpu_baseline(n, with_reference_kernel=not args.primary_only)
             out["cpu_baseline"] = base
             if not args.primary_only:
                 # the same single-thread oracle at configs #1 / #2's sizes (2 000 / 50 sweeps)

@@ -23,8 +23,12 @@
  * lines cut out -- structs, WeightedHarmonicMean, DiscretizeMatrix2D[_ImpSolid],
  * Residual, FloodFill, calcPorosity, calcFracts3D -- and every function of
  * this file that restates one of those is pinned to it BIT FOR BIT
- * (tests/test_ref_host.py).  The sweep kernels and the stopping rule are CUDA
- * code; for them the oracle is pinned against what /root/reference holds:
+ * (tests/test_ref_host.py).  The two sweep KERNELS (cuh:69-118) are CUDA
+ * kernel language = HIP kernel language: hipcc compiles their text for gfx950
+ * (oracle/_ref/ref_kernel) and oracle_sweep_sor / oracle_sweep_v1 are pinned
+ * to them bit for bit on the GPU box (tests/test_ref_kernel.py).  The host
+ * loop with its stopping rule sits between CUDA API calls and is not
+ * buildable; for it the oracle is pinned against what /root/reference holds:
  *   (i)   the reference's own stb_image.h, compiled as it lies by
  *         tests/golden/make_stb_fixture.py: the decoded bytes of 00000.jpg are
  *         the pixel fixture every config-#1 golden here is derived from;

@@ -328,3 +328,32 @@ def ref_fractions(pix, D, DCS, DCF, tmpdir=None):
 def ref_whm(w1, w2, x1, x2):
     out, _ = _ref_run(["whm", repr(w1), repr(w2), repr(x1), repr(x2)], None)
     return float(out)
+
+
+# ---- oracle/_ref/ref_kernel[_fma]: the reference's OWN sweep kernels (cuh:69-118), compiled by hipcc for gfx950 from their own
+# text (oracle/ref_kernel_probe.hip, oracle/Makefile) -- needs a GPU to run. -------------------------------------------------
+def have_ref_kernel():
+    return os.access(os.path.join(ORACLE_DIR, "_ref", "ref_kernel"), os.X_OK)
+
+
+def ref_sweeps(A, b, x, nsweeps, which=0, fma=False, tmpdir=None, timing=False):
+    """nsweeps launches of the reference's updateX_SOR (which = 0) or updateX_V1 (1) on the GPU, with the reference's grid and its
+    x <- xNew copy after every launch (cuh:1237-1281).  fma: the build with hipcc's default contraction."""
+    import subprocess
+    import tempfile
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    ny, nx = x.shape
+    exe = os.path.join(ORACLE_DIR, "_ref", "ref_kernel_fma" if fma else "ref_kernel")
+    with tempfile.TemporaryDirectory(dir=tmpdir) as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(np.array([nx, ny, int(nsweeps), int(which)], dtype=np.int32).tobytes())
+            f.write(np.ascontiguousarray(A, dtype=np.float64).tobytes())
+            f.write(np.ascontiguousarray(b, dtype=np.float64).tobytes())
+            f.write(x.tobytes())
+        r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        out = np.fromfile(fout, dtype=np.float64).reshape(ny, nx)
+        if timing:
+            return out, float(r.stdout.split()[1])               # "loop_ms <ms> sweeps <n>"
+        return out
