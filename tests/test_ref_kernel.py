@@ -136,3 +136,27 @@ def test_4096_against_the_references_own_code(pkg, oracle, tmp_path):
         assert s.plan()["tb_T"] == 8 and s.plan()["tb_impl"] == 1
         got = s.get_field()
     assert rel_l2(got, want) <= 1e-6 and np.array_equal(got, want)
+
+
+def test_config1_field_after_110001_launches_of_the_references_kernel(pkg, oracle, img00000, recorded, tmp_path):
+    """Config #1 in full: the reference's image, the reference's assembly, 110 001 launches of the reference's updateX_SOR on the
+    MI355X (the count at which the reference's stopping rule fires, reproduced by deff_solve) -- the field equals the committed
+    golden field (generated by the oracle in an earlier round) and the field deff_solve leaves, bit for bit; the Deff evaluated
+    from it by the oracle's restatement of cuh:1252-1263 is the recorded value."""
+    import os
+    from conftest import GOLDEN
+    gold = np.load(os.path.join(GOLDEN, "img00000_field.npy"))
+    D = oracle.fill_D_2phase(img00000, 1.0, 1e-3)
+    A, b = ob.ref_discretize(D, 0.0, 1.0, tmpdir=tmp_path)
+    want = ob.ref_sweeps(A, b, oracle.linear_guess(128, 128, 0.0, 1.0), 110001, tmpdir=tmp_path)
+    assert np.array_equal(want, gold)
+    with pkg.Solver(128, 128) as s:
+        s.set_image(img00000)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        r = s.solve(1e-6, 500000)
+        got = s.get_field()
+    assert r.iters == 110001 == recorded["img00000_2phase_batch"]["iters"]
+    assert np.array_equal(got, want)
+    # the Deff of the reference's loop is the value at its LAST CHECK (sweep 110 001 = this field)
+    assert oracle.flux_deff(want, D, 0.0, 1.0)[0] == r.deff_raw == recorded["img00000_2phase_batch"]["deff_build_b"]
