@@ -1,7 +1,8 @@
 """Pins the CPU oracle (oracle/deff_oracle.c) before anything trusts it.
 
-The reference has no test suite and cannot be built in this image, so the pins
-are (a) the reference outputs the survey stage recorded (SURVEY.md 6/8c,
+The reference has no test suite and its host loop cannot be built in this image
+(its host-only functions and its kernels can: tests/test_ref_host.py,
+tests/test_ref_kernel.py), so the pins here are (a) the reference outputs the survey stage recorded (SURVEY.md 6/8c,
 BASELINE.md 2; copied in tests/golden/reference_recorded.json), (b) the
 analytic known-answer cases of the reference's documentation (doc 5.3, with
 the sweep counts the reference's own stopping rule produced), and (c) the
