@@ -166,3 +166,83 @@ def run_sequence(pkg, ob, seed):
 @pytest.mark.parametrize("seed", range(40))
 def test_random_call_sequences_match_the_oracle(pkg, oracle, seed):
     run_sequence(pkg, oracle, 1000 + seed)
+
+
+def run_slab_sequence(pkg, ob, seed):
+    """The same idea for one image split into row slabs (deff_slab_group_*, N slabs on one GPU: peer copies between their
+    buffers, one exchange of 8 halo rows per pass, optionally overlapped with the interior): random sizes (odd widths, slabs
+    that differ by a row), slab counts, sweeps per pass, overlap modes and call sequences; every read against the oracle."""
+    rng = np.random.default_rng(seed)
+    nx = int(rng.integers(8, 420))
+    nslabs = int(rng.integers(2, 5))
+    ny = int(rng.integers(8 * nslabs, 8 * nslabs + 500))
+    m = Model(ob, nx, ny, 1, rng)
+    log = [f"nx {nx} ny {ny} slabs {nslabs}"]
+    with pkg.SlabGroup(nx, ny, [0] * nslabs) as g:
+        m.new_image()
+        g.set_image(m.pix[0])
+        for step in range(16):
+            ops = ["image", "assemble", "tune"]
+            if m.kind is not None:
+                ops += ["init", "set_field"]
+                if m.x is not None:
+                    ops += ["sweeps", "sweeps", "solve", "flux", "get"]
+            op = ops[rng.integers(len(ops))]
+            if op == "image":
+                m.new_image()
+                g.set_image(m.pix[0])
+                log.append("image")
+            elif op == "assemble":
+                kind = ["2p", "2p", "3p"][rng.integers(3)]
+                Ds, Df, Dg = [(1e-3, 1.0, 10.0), (1e-2, 1.0, 50.0), (0.1, 2.0, 7.0)][rng.integers(3)]
+                CL, CR = [(0.0, 1.0), (0.25, 0.75)][rng.integers(2)]
+                m.assemble(kind, Ds, Df, Dg, CL, CR)
+                if kind == "2p":
+                    g.assemble_2phase(Ds, Df, CL, CR)
+                else:
+                    g.assemble_3phase(Ds, Df, Dg, CL, CR)
+                log.append(f"assemble {kind} {Ds} {Df} {CL}")
+            elif op == "tune":
+                if rng.random() < 0.5:
+                    v = int(rng.choice([0, 1, 2, 4, 8])); g.set_tuning("tb_T", v); log.append(f"tb_T {v}")
+                else:
+                    v = int(rng.choice([0, 1, 2])); g.set_tuning("slab_overlap", v); log.append(f"slab_overlap {v}")
+            elif op == "init":
+                g.init_linear(m.CL, m.CR)
+                m.x = [ob.linear_guess(nx, ny, m.CL, m.CR)]
+                log.append("init")
+            elif op == "set_field":
+                m.x = [rng.random((ny, nx))]
+                g.set_field(m.x[0])
+                log.append("set_field")
+            elif op == "sweeps":
+                k = int(rng.choice([1, 3, 8, 17, 40]))
+                omega, kern = [(2.0 / 3.0, 0), (1.0, 1)][rng.integers(2)]
+                g.sweeps(k, omega)
+                m.x = [ob.sweeps(m.A[0], m.b[0], m.x[0], k, kernel=kern, omega=omega)]
+                log.append(f"sweeps {k} {omega:.3f}")
+                assert np.array_equal(g.get_field(), m.x[0]), (seed, log)
+            elif op == "solve":
+                tol = float(rng.choice([1e-2, 1e-4, 1e-12]))
+                max_iter = int(rng.choice([1, 7, 100, 101, 130]))
+                ce = int(rng.choice([7, 50, 100]))
+                r = g.solve(tol, max_iter, check_every=ce)
+                log.append(f"solve {tol} {max_iter} {ce}")
+                it, deff, conv, x, MFL, MFR = ob.jacobi(m.A[0], m.b[0], m.x[0], m.D[0], m.CL, m.CR, tol, max_iter, check_every=ce)
+                assert (r.iters, r.deff_raw, r.conv) == (it, deff, conv), (seed, log)
+                m.x = [x]
+                assert np.array_equal(g.get_field(), x), (seed, log)
+            elif op == "flux":
+                d, MFL, MFR = g.flux()
+                want, L, R = ob.flux_deff(m.x[0], m.D[0], m.CL, m.CR)
+                assert d == want and np.array_equal(MFL, L) and np.array_equal(MFR, R), (seed, log)
+                log.append("flux")
+            elif op == "get":
+                assert np.array_equal(g.get_field(), m.x[0]), (seed, log)
+                log.append("get")
+    return log
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_call_sequences_on_row_slabs_match_the_oracle(pkg, oracle, seed):
+    run_slab_sequence(pkg, oracle, 5000 + seed)
