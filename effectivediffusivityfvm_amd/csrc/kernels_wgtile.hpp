@@ -430,13 +430,10 @@ __device__ __forceinline__ void wgl_sweeps(double2 (&xr)[R], const unsigned *cod
                     // 1280^2 +4 %, 1792^2 +5 %, 2048^2 +12 %, 256 x 128^2 +7 %.
                     constexpr int PS = LUT_PLANE_STRIDE * 8;
                     double aSp0 = 0.0, aSp1 = 0.0;
-#pragma unroll
-                    for (int r = 1; r <= R - 2; ++r) {
-                        const double2 cur = xr[r];
-                        const unsigned cw = codes[r * 64];
+                    // the row's own coefficients (7 lookups; aW[1] and aN come from the symmetry)
+                    auto lookup7 = [&](const unsigned cw, TbCoef &k) __attribute__((always_inline)) {
                         const char *b0 = reinterpret_cast<const char *>(lut_t) + (cw & 0xFFFFu);
                         const char *b1 = reinterpret_cast<const char *>(lut_t) + (cw >> 16);
-                        TbCoef k;
                         k.c0[0] = *reinterpret_cast<const double *>(b0);
                         k.c0[1] = *reinterpret_cast<const double *>(b1);
                         k.aW[0] = *reinterpret_cast<const double *>(b0 + PS);
@@ -445,19 +442,32 @@ __device__ __forceinline__ void wgl_sweeps(double2 (&xr)[R], const unsigned *cod
                         k.aW[1] = k.aE[0];
                         k.aS[0] = *reinterpret_cast<const double *>(b0 + 3 * PS);
                         k.aS[1] = *reinterpret_cast<const double *>(b1 + 3 * PS);
-                        if (r == 1) {
-                            k.aN[0] = *reinterpret_cast<const double *>(b0 + 4 * PS);
-                            k.aN[1] = *reinterpret_cast<const double *>(b1 + 4 * PS);
-                        } else {
-                            k.aN[0] = aSp0;
-                            k.aN[1] = aSp1;
-                        }
                         if constexpr (WALL) {
                             k.b[0] = *reinterpret_cast<const double *>(b0 + 5 * PS);
                             k.b[1] = *reinterpret_cast<const double *>(b1 + 5 * PS);
                         } else {
                             k.b[0] = 0.0;
                             k.b[1] = 0.0;
+                        }
+                    };
+                    // The codes of row r + 1 are fetched from LDS while row r is computed (one VGPR): without it every row starts with
+                    // two dependent LDS round trips, code -> coefficients.  +2 % at 1152^2, +0.5...2 % at 1536^2...2048^2, one process
+                    // per build.  (Fetching the next row's COEFFICIENTS ahead as well -- 14 VGPRs, affordable up to R = 5 -- measured
+                    // -1 %: at four waves per SIMD the lookups' latency is already covered.)
+                    unsigned cw_next = codes[64];
+#pragma unroll
+                    for (int r = 1; r <= R - 2; ++r) {
+                        const double2 cur = xr[r];
+                        const unsigned cw = cw_next;
+                        if (r < R - 2) cw_next = codes[(r + 1) * 64];
+                        TbCoef k;
+                        lookup7(cw, k);
+                        if (r == 1) {
+                            k.aN[0] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lut_t) + (cw & 0xFFFFu) + 4 * PS);
+                            k.aN[1] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lut_t) + (cw >> 16) + 4 * PS);
+                        } else {
+                            k.aN[0] = aSp0;
+                            k.aN[1] = aSp1;
                         }
                         aSp0 = k.aS[0];
                         aSp1 = k.aS[1];
