@@ -33,6 +33,25 @@ def usage():
     return out
 
 
+@pytest.fixture(scope="module")
+def usage_residual():
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                        "-fno-fast-math", "-fvisibility=hidden", "-Wno-unused-function",
+                        "-Rpass-analysis=kernel-resource-usage", "-c", "-o", os.devnull, "api_residual.hip"],
+                       cwd=CSRC, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" ")[0]] = int(m.group(2))
+    return out
+
+
 def kernels(usage, prefix):
     got = {k: v for k, v in usage.items() if k.startswith(prefix)}
     assert got, prefix
@@ -120,3 +139,16 @@ def test_single_sweep_kernels_are_light(usage):
     for prefix in ("_ZN4deff16k_sweep_explicitI", "_ZN4deff15k_sweep_matfreeI", "_ZN4deff14k_sweep_scalarI"):
         for name, u in kernels(usage, prefix).items():
             assert u["ScratchSize"] == 0 and u["Occupancy"] >= 4, (name, u)
+
+
+def test_residual_kernels_are_light(usage_residual):
+    """k_residual_classes<PHASES, FAST>: a streaming reduction that must hide HBM latency with occupancy -- at least 4 waves per
+    SIMD (<= 128 VGPRs), no scratch, a 192-byte table in LDS; the plane and final kernels likewise."""
+    seen = 0
+    for name, u in usage_residual.items():
+        if "k_residual_classes" in name:
+            seen += 1
+            assert u["Occupancy"] >= 4 and u["VGPRs"] <= 128 and u["ScratchSize"] == 0 and u["LDS"] <= 256, (name, u)
+        if "k_residual_plane" in name or "k_residual_final" in name:
+            assert u["ScratchSize"] == 0 and u["Occupancy"] >= 4, (name, u)
+    assert seen == 4
