@@ -20,8 +20,11 @@
 // What differs from the reference is only the ORDER of the final sum (the reference adds the cells serially, row-major):
 // a lane adds its cells top to bottom (first cell of its pair, then the second), the 64 lane sums of a wave are combined by a
 // fixed DPP tree (row_shr 1, 2, 3, 4, 8, then row_bcast 15 and 31: lane 63 holds the wave's sum), and k_residual_final
-// adds the waves' partial sums of an image in index order l, l + 64, ... per lane and through the same tree.  Deterministic
-// (same bits every run, any grid), ~1e-16 relative from the serial order.
+// (one workgroup of 16 waves per image) has thread t add the waves' partial sums t, t + 1024, ... in that order, the same tree
+// per wave, and thread 0 the 16 wave sums in wave order.  The order depends on the launch geometry only: same bits on every
+// call.  Of the two orders the serial one is the less accurate (it drifts from the exactly added terms by up to n * 2^-53; a
+// tree loses ~log2 n ulps): tests compare with the oracle's per-cell doubles added in long double (1e-13) and with its serial
+// sum within that sum's own error bound (tests/oracle_binding.py: assert_residual).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
