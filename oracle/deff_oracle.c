@@ -27,8 +27,12 @@
  * kernel language = HIP kernel language: hipcc compiles their text for gfx950
  * (oracle/_ref/ref_kernel) and oracle_sweep_sor / oracle_sweep_v1 are pinned
  * to them bit for bit on the GPU box (tests/test_ref_kernel.py).  The host
- * loop with its stopping rule sits between CUDA API calls and is not
- * buildable; for it the oracle is pinned against what /root/reference holds:
+ * loop's LOGIC lines (literals, while / check conditions, Deff evaluation,
+ * counter) are included verbatim as fragments into a harness that moves the
+ * data through HIP (oracle/_ref/ref_loop): oracle_jacobi is pinned to it --
+ * counts, last-check Deff, conv, fields -- on config #1 and the rule's corner
+ * cases (tests/test_ref_loop.py).  The drivers stay a restatement; for them
+ * (and historically for everything) the pins are what /root/reference holds:
  *   (i)   the reference's own stb_image.h, compiled as it lies by
  *         tests/golden/make_stb_fixture.py: the decoded bytes of 00000.jpg are
  *         the pixel fixture every config-#1 golden here is derived from;

@@ -357,3 +357,32 @@ def ref_sweeps(A, b, x, nsweeps, which=0, fma=False, tmpdir=None, timing=False):
         if timing:
             return out, float(r.stdout.split()[1])               # "loop_ms <ms> sweeps <n>"
         return out
+
+
+# ---- oracle/_ref/ref_loop: the reference's host loop JacobiGPU (cuh:1163-1314) -- its own logic lines as fragments in a harness
+# whose own lines move data through HIP (oracle/ref_loop_probe.hip) -- needs a GPU to run. ------------------------------------
+def have_ref_loop():
+    return os.access(os.path.join(ORACLE_DIR, "_ref", "ref_loop"), os.X_OK)
+
+
+def ref_jacobi(A, b, x0, D, CL, CR, tol, max_iter, DCfluid=1.0, tmpdir=None):
+    """The reference's JacobiGPU on the GPU: (iters, deff_raw, conv, field, MFL, MFR, gpu_ms).  The check interval is the
+    reference's literal 10 000."""
+    import struct
+    import subprocess
+    import tempfile
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    ny, nx = x0.shape
+    n = nx * ny
+    with tempfile.TemporaryDirectory(dir=tmpdir) as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(np.array([nx, ny], dtype=np.int32).tobytes() + struct.pack("l", int(max_iter)) + np.array([tol, CL, CR, DCfluid]).tobytes())
+            for a in (A, b, x0, D):
+                f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+        r = subprocess.run([os.path.join(ORACLE_DIR, "_ref", "ref_loop"), fin, fout], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr
+        raw = open(fout, "rb").read()
+    iters = struct.unpack("l", raw[:8])[0]
+    v = np.frombuffer(raw[8:], dtype=np.float64)
+    return iters, float(v[0]), float(v[1]), v[3:3 + n].reshape(ny, nx).copy(), v[3 + n:3 + n + ny].copy(), v[3 + n + ny:3 + n + 2 * ny].copy(), float(v[2])
