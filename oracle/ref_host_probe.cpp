@@ -6,6 +6,7 @@
  *             cuh:17-68    options, simulationInfo, meshInfo, coordPair
  *             cuh:119-903  printOptions, the CSV writers, readInputFile, readImage, WeightedHarmonicMean, calcPorosity,
  *                          calcFracts3D, Residual, createCMAP, FloodFill, DiscretizeMatrix2D_ImpSolid, DiscretizeMatrix2D
+ *             + three loops of the drivers as fragments (the D fills and the linear guess: see `fill` / `guess` below)
  *     dropped cuh:15-16    #include "cuda_runtime.h" / "cuda.h"
  *             cuh:69-118   the two __global__ kernels
  *             cuh:904-end  initializeGPU, unInitializeGPU, the Jacobi loops (CUDA calls throughout) and the four drivers
@@ -18,11 +19,31 @@
  *   ref_host residual  in.bin             in: int nx, ny; double CL, CR; x[n]; D[n]                           prints %.17g
  *   ref_host floodfill in.bin out.bin     in: int nx, ny; unsigned Grid[n]                                    out: Grid[n]
  *   ref_host fractions in.bin             in: int nx, ny; double Ds, Df; uint8 pix[n]; D[n]                   prints porosity SVF LVF
+ *   ref_host fill      in.bin out.bin     in: int W, H; int ampX, ampY, phases; double DCS, DCF, DCG; uint8 pix[W*H]   out: D[n]
+ *                                         (the drivers' own loops, included as FRAGMENTS: BatchSim's 2-phase fill cuh:1988-2000,
+ *                                         SingleSim3Phase's 3-class fill cuh:1510-1531 -- mesh amplification included)
+ *   ref_host guess     in.bin out.bin     in: int nx, ny; double CL, CR                                      out: x[n]  (cuh:1955-1959)
  *   ref_host whm w1 w2 x1 x2                                                                                   prints %.17g
  *   ref_host input file                   readInputFile(file): prints the 17 options, one per line */
 #include "ref_host_part.hpp"
 
 static bool rd(FILE *f, void *p, size_t bytes) { return fread(p, 1, bytes, f) == bytes; }
+
+// The drivers keep these loops inline, between file handling and CUDA calls; the loops themselves are plain C++ over local
+// variables.  Each function below declares those variables under the drivers' names and #includes the reference's lines.
+static void driver_fill_2phase(double *D, double *MFL, double *MFR, meshInfo mesh, options opts, simulationInfo myImg, double DCF, double DCS)
+{
+#include "ref_frag_fill2.inc"        /* cuh:1988-2000 */
+}
+static void driver_fill_3phase(double *D, double *MFL, double *MFR, meshInfo mesh, options opts, simulationInfo myImg, double DCF, double DCS,
+                               double DCG_Temp)
+{
+#include "ref_frag_fill3.inc"        /* cuh:1510-1531 */
+}
+static void driver_linear_guess(double *ConcentrationDist, meshInfo mesh, options opts)
+{
+#include "ref_frag_guess.inc"        /* cuh:1955-1959 */
+}
 
 int main(int argc, char **argv)
 {
@@ -44,6 +65,31 @@ int main(int argc, char **argv)
     if (argc < 3) return 2;
     FILE *f = fopen(argv[2], "rb");
     if (!f) return 2;
+    if (cmd == "fill" && argc == 4) {
+        int hdr[5];
+        double dc[3];
+        if (!rd(f, hdr, 20) || !rd(f, dc, 24)) return 2;
+        const int W = hdr[0], H = hdr[1];
+        options o;
+        memset(&o, 0, sizeof o);
+        o.MeshIncreaseX = hdr[2]; o.MeshIncreaseY = hdr[3];
+        std::vector<unsigned char> pix((size_t)W * H);
+        if (!rd(f, pix.data(), pix.size())) return 2;
+        simulationInfo img;
+        memset(&img, 0, sizeof img);
+        img.Width = W; img.Height = H; img.target_data = pix.data();
+        meshInfo mesh;
+        mesh.numCellsX = W * o.MeshIncreaseX; mesh.numCellsY = H * o.MeshIncreaseY;          // cuh:1907-1908
+        mesh.nElements = mesh.numCellsX * mesh.numCellsY;
+        std::vector<double> D((size_t)mesh.nElements), MFL(mesh.numCellsY), MFR(mesh.numCellsY);
+        if (hdr[4] == 2) driver_fill_2phase(D.data(), MFL.data(), MFR.data(), mesh, o, img, dc[1], dc[0]);
+        else driver_fill_3phase(D.data(), MFL.data(), MFR.data(), mesh, o, img, dc[1], dc[0], dc[2]);
+        FILE *g = fopen(argv[3], "wb");
+        if (!g) return 2;
+        fwrite(D.data(), 8, D.size(), g);
+        fclose(g);
+        return 0;
+    }
     int nx = 0, ny = 0;
     if (!rd(f, &nx, 4) || !rd(f, &ny, 4) || nx < 1 || ny < 1) return 2;
     const size_t n = (size_t)nx * ny;
@@ -64,6 +110,16 @@ int main(int argc, char **argv)
         if (!g) return 2;
         fwrite(A.data(), 8, n * 5, g);
         fwrite(b.data(), 8, n, g);
+        fclose(g);
+        return 0;
+    }
+    if (cmd == "guess" && argc == 4) {
+        if (!rd(f, &o.CLeft, 8) || !rd(f, &o.CRight, 8)) return 2;
+        std::vector<double> x(n);
+        driver_linear_guess(x.data(), mesh, o);
+        FILE *g = fopen(argv[3], "wb");
+        if (!g) return 2;
+        fwrite(x.data(), 8, n, g);
         fclose(g);
         return 0;
     }

@@ -325,6 +325,22 @@ def ref_fractions(pix, D, DCS, DCF, tmpdir=None):
     return tuple(float(v) for v in out.split())
 
 
+def ref_fill_D(pix, DCS, DCF, DCG=0.0, ampX=1, ampY=1, phases=2, tmpdir=None):
+    """The drivers' own D-fill loops (BatchSim cuh:1988-2000 / SingleSim3Phase cuh:1510-1531), mesh amplification included."""
+    pix = np.ascontiguousarray(pix, dtype=np.uint8)
+    H, W = pix.shape
+    payload = np.array([W, H, ampX, ampY, phases], dtype=np.int32).tobytes() + np.array([DCS, DCF, DCG]).tobytes() + pix.tobytes()
+    _, data = _ref_run(["fill", "@in", "@out"], tmpdir, payload, True)
+    return np.frombuffer(data, dtype=np.float64).reshape(H * ampY, W * ampX).copy()
+
+
+def ref_linear_guess(nx, ny, CL, CR, tmpdir=None):
+    """The drivers' linear initial guess (cuh:1955-1959)."""
+    payload = np.array([nx, ny], dtype=np.int32).tobytes() + np.array([CL, CR]).tobytes()
+    _, data = _ref_run(["guess", "@in", "@out"], tmpdir, payload, True)
+    return np.frombuffer(data, dtype=np.float64).reshape(ny, nx).copy()
+
+
 def ref_whm(w1, w2, x1, x2):
     out, _ = _ref_run(["whm", repr(w1), repr(w2), repr(x1), repr(x2)], None)
     return float(out)
