@@ -15,7 +15,7 @@
  * No CUDA header or library is stood in for: nothing named cuda* exists in this build.  The kernels come from
  * ref_kernel_part.hpp (cuh:17-118, see ref_kernel_probe.hip).
  *
- *   ref_loop in.bin out.bin
+ *   ref_loop in.bin out.bin [precond]          (precond: JacobiGPUPreCond, cuh:1024-1160, built the same way -- see below)
  *     in : int nx, ny; long MAX_ITER; double tol, CL, CR, DCfluid; double A[n*5], b[n], x[n], D[n]
  *     out: long iters; double deff, conv, gpu_ms; double x[n], MFL[ny], MFR[ny] */
 #include <hip/hip_runtime.h>
@@ -58,9 +58,34 @@ static int JacobiGPU(double *arr, double *sol, double *x_vec, double *temp_x_vec
     return iterCount;                                                                            /* cuh:1313 */
 }
 
+/* JacobiGPUPreCond (cuh:1024-1160), the loop of the 3-phase continuation stages: the same construction from its own lines
+ *     ref_pre_decl.inc cuh:1028-1054, ref_pre_while.inc cuh:1087-1088, ref_pre_launch.inc cuh:1092, ref_pre_if.inc cuh:1098-1099,
+ *     ref_pre_deff.inc cuh:1107-1128, ref_pre_count.inc cuh:1140-1142  (it writes nothing into myImg and returns iterCount) */
+static int JacobiGPUPreCond(double *arr, double *sol, double *x_vec, double *temp_x_vec, options opts,
+                            double *d_x_vec, double *d_temp_x_vec, double *d_Coeff, double *d_RHS, double *MFL, double *MFR, double *D,
+                            meshInfo mesh, simulationInfo *myImg)                            /* signature: cuh:1024-1025 */
+{
+#include "ref_pre_decl.inc"
+    (void)Res; (void)dy; (void)str; (void)myImg;
+    hipMemcpy(d_temp_x_vec, temp_x_vec, sizeof(double) * nRows, hipMemcpyHostToDevice);          /* ours, for cuh:1058 */
+    hipMemcpy(d_RHS, sol, sizeof(double) * nRows, hipMemcpyHostToDevice);                        /* ours, for cuh:1065 */
+    hipMemcpy(d_Coeff, arr, sizeof(double) * nRows * nCols, hipMemcpyHostToDevice);              /* ours, for cuh:1072 */
+#include "ref_pre_while.inc"
+#include "ref_pre_launch.inc"
+        hipDeviceSynchronize();                                                                  /* ours, for cuh:1094 */
+#include "ref_pre_if.inc"
+            hipMemcpy(x_vec, d_x_vec, sizeof(double) * nRows, hipMemcpyDeviceToHost);            /* ours, for cuh:1100 */
+#include "ref_pre_deff.inc"
+        hipMemcpy(d_temp_x_vec, d_x_vec, sizeof(double) * nRows, hipMemcpyDeviceToDevice);       /* ours, for cuh:1133 */
+#include "ref_pre_count.inc"
+    hipMemcpy(x_vec, d_x_vec, sizeof(double) * nRows, hipMemcpyDeviceToHost);                    /* ours, for cuh:1150 */
+    return iterCount;                                                                            /* cuh:1159 */
+}
+
 int main(int argc, char **argv)
 {
-    if (argc != 3) { fprintf(stderr, "usage: ref_loop in.bin out.bin\n"); return 2; }
+    const bool precond = argc == 4 && !strcmp(argv[3], "precond");
+    if (argc != 3 && !precond) { fprintf(stderr, "usage: ref_loop in.bin out.bin [precond]\n"); return 2; }
     FILE *f = fopen(argv[1], "rb");
     int dims[2];
     long max_iter;
@@ -83,7 +108,9 @@ int main(int argc, char **argv)
     if (hipMalloc((void **)&d_x, n * 8) != hipSuccess || hipMalloc((void **)&d_tmp, n * 8) != hipSuccess ||
         hipMalloc((void **)&d_A, n * 40) != hipSuccess || hipMalloc((void **)&d_b, n * 8) != hipSuccess) return 3;
     hipMemset(d_x, 0, n * 8);                                                                    /* initializeGPU zero-fills, cuh:946-973 */
-    const long iters = JacobiGPU(A.data(), b.data(), x.data(), tmp.data(), opts, d_x, d_tmp, d_A, d_b, MFL.data(), MFR.data(), D.data(), mesh, &img);
+    const long iters = precond
+        ? JacobiGPUPreCond(A.data(), b.data(), x.data(), tmp.data(), opts, d_x, d_tmp, d_A, d_b, MFL.data(), MFR.data(), D.data(), mesh, &img)
+        : JacobiGPU(A.data(), b.data(), x.data(), tmp.data(), opts, d_x, d_tmp, d_A, d_b, MFL.data(), MFR.data(), D.data(), mesh, &img);
     FILE *g = fopen(argv[2], "wb");
     if (!g) return 2;
     const double head[3] = {img.deff, img.conv, img.gpuTime};

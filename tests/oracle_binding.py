@@ -381,9 +381,9 @@ def have_ref_loop():
     return os.access(os.path.join(ORACLE_DIR, "_ref", "ref_loop"), os.X_OK)
 
 
-def ref_jacobi(A, b, x0, D, CL, CR, tol, max_iter, DCfluid=1.0, tmpdir=None):
-    """The reference's JacobiGPU on the GPU: (iters, deff_raw, conv, field, MFL, MFR, gpu_ms).  The check interval is the
-    reference's literal 10 000."""
+def ref_jacobi(A, b, x0, D, CL, CR, tol, max_iter, DCfluid=1.0, tmpdir=None, precond=False):
+    """The reference's JacobiGPU (precond: JacobiGPUPreCond, which leaves deff / conv / gpu_ms untouched = 0) on the GPU:
+    (iters, deff_raw, conv, field, MFL, MFR, gpu_ms).  The check interval is the reference's literal 10 000."""
     import struct
     import subprocess
     import tempfile
@@ -396,7 +396,8 @@ def ref_jacobi(A, b, x0, D, CL, CR, tol, max_iter, DCfluid=1.0, tmpdir=None):
             f.write(np.array([nx, ny], dtype=np.int32).tobytes() + struct.pack("l", int(max_iter)) + np.array([tol, CL, CR, DCfluid]).tobytes())
             for a in (A, b, x0, D):
                 f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
-        r = subprocess.run([os.path.join(ORACLE_DIR, "_ref", "ref_loop"), fin, fout], capture_output=True, text=True, timeout=900)
+        r = subprocess.run([os.path.join(ORACLE_DIR, "_ref", "ref_loop"), fin, fout] + (["precond"] if precond else []),
+                           capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr
         raw = open(fout, "rb").read()
     iters = struct.unpack("l", raw[:8])[0]

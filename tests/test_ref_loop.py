@@ -95,3 +95,42 @@ def test_1024_first_checks_against_the_references_own_loop(pkg, oracle, kernel, 
     r, got = solve_hip(pkg, pix, 1e-3, 1.0, 0.0, 1.0, 1e-9, 20001, kernel=kernel)
     assert it == 20001 and (r.iters, r.deff_raw, r.conv) == (it, deff, conv)
     assert np.array_equal(got, x) and np.array_equal(r.MFL, MFL) and np.array_equal(r.MFR, MFR)
+
+
+def test_3phase_as_shipped_through_the_references_own_loops(pkg, oracle, img00000, recorded, tmp_path):
+    """Row a14 and the configuration the reference ships (3 phases, Ds 0, Df 1, Dg 1 237 500, tol 1e-5) on 00000.jpg, with the
+    reference's code on every numeric line: its flood fill, its 3-class D fill, its DiscretizeMatrix2D_ImpSolid, six stages of its
+    JacobiGPUPreCond (DCG = 10 ... 1e6, tolerance x 10, MAX_ITER 1e6) and its JacobiGPU, each warm-started from the previous
+    field (x_vec is in / out) -- only the ramp's control flow (cuh:1492-1549: g = 10; g < DCG; g *= 10) is written here.
+    Stage counts [80 001, 10 001 x 5, 10 001], Deff 224673.61044289195 (/ Df), conv: the recorded numbers, the oracle's and the
+    library's (batch.solve_image_3phase), bit for bit; the final fields too."""
+    from effectivediffusivityfvm_amd import batch
+    rec = recorded["img00000_3phase_as_shipped"]
+    o = rec["options"]
+    Ds, Df, Dg, CL, CR, tol, max_iter = o["Ds"], o["Df"], o["Dg"], o["CL"], o["CR"], o["tol"], o["max_iter"]
+    grid = ob.ref_floodfill((img00000 > 200).astype(np.uint32), tmpdir=tmp_path)
+    x = ob.ref_linear_guess(128, 128, CL, CR, tmpdir=tmp_path)
+    stages = []
+    g = 10.0
+    with np.errstate(all="ignore"):
+        while g < Dg:                                                                # cuh:1492
+            D = ob.ref_fill_D(img00000, Ds, Df, g, phases=3, tmpdir=tmp_path)
+            A, b = ob.ref_discretize(D, CL, CR, grid=grid, tmpdir=tmp_path)
+            it, _, _, x, _, _, _ = ob.ref_jacobi(A, b, x, D, CL, CR, tol * 10, 1000000, tmpdir=tmp_path, precond=True)   # cuh:1503, 1539
+            stages.append(it)
+            g = g * 10                                                               # cuh:1548
+        D = ob.ref_fill_D(img00000, Ds, Df, Dg, phases=3, tmpdir=tmp_path)
+        A, b = ob.ref_discretize(D, CL, CR, grid=grid, tmpdir=tmp_path)
+        it, deff, conv, x, _, _, _ = ob.ref_jacobi(A, b, x, D, CL, CR, tol, max_iter, DCfluid=Df, tmpdir=tmp_path)      # cuh:1590
+    stages.append(it)
+    assert stages == rec["stage_sweeps"]
+    assert deff / Df == rec["deff"] and conv == rec["conv"]
+    with np.errstate(all="ignore"):
+        want = oracle.solve_3phase(img00000, Ds, Df, Dg, CL, CR, tol, max_iter)
+    assert want["stage_sweeps"] == stages and want["deff"] == deff / Df and want["conv"] == conv
+    assert np.array_equal(want["field"], x, equal_nan=True)
+    with pkg.Solver(128, 128) as s:
+        got = batch.solve_image_3phase(s, img00000, Ds, Df, Dg, CL, CR, tol, max_iter)
+        field = s.get_field()
+    assert got["stage_sweeps"] == stages and got["deff"] == deff / Df and got["conv"] == conv
+    assert np.array_equal(field, x, equal_nan=True)
