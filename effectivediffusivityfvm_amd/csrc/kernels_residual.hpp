@@ -24,7 +24,7 @@
 // per wave, and thread 0 the 16 wave sums in wave order.  The order depends on the launch geometry only: same bits on every
 // call.  Of the two orders the serial one is the less accurate (it drifts from the exactly added terms by up to n * 2^-53; a
 // tree loses ~log2 n ulps): tests compare with the oracle's per-cell doubles added in long double (1e-13) and with its serial
-// sum within that sum's own error bound (tests/oracle_binding.py: assert_residual).
+// sum within that sum's own error bound (the tests' assert_residual).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
