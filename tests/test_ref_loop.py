@@ -134,3 +134,20 @@ def test_3phase_as_shipped_through_the_references_own_loops(pkg, oracle, img0000
         field = s.get_field()
     assert got["stage_sweeps"] == stages and got["deff"] == deff / Df and got["conv"] == conv
     assert np.array_equal(field, x, equal_nan=True)
+
+
+def test_single_sim_dcf_ramp_through_the_references_own_loop(oracle, img00000, tmp_path):
+    """SingleSim's DCF continuation (cuh:1759-1817) for Df = 1e4 on 00000.jpg, MaxIter 30 001: stages DCF = 100 and 1e4, each the
+    drivers' own D fill, the reference's assembly and its JacobiGPU, warm-started through x_vec; the ramp's control flow is the
+    oracle binding's restatement (solve_single_2phase_ramp), whose per-stage counts, Deff / DCF, conv and final field must come out
+    of the reference's code too."""
+    want = oracle.solve_single_2phase_ramp(img00000, 1e-3, 1e4, 0.0, 1.0, 1e-6, 30001)
+    x = ob.ref_linear_guess(128, 128, 0.0, 1.0, tmpdir=tmp_path)
+    got = []
+    for DCF in (100.0, 1e4):                                                         # std::pow(100, count), clipped to Df
+        D = ob.ref_fill_D(img00000, 1e-3, DCF, tmpdir=tmp_path)
+        A, b = ob.ref_discretize(D, 0.0, 1.0, tmpdir=tmp_path)
+        it, deff, conv, x, _, _, _ = ob.ref_jacobi(A, b, x, D, 0.0, 1.0, 1e-6, 30001, DCfluid=DCF, tmpdir=tmp_path)
+        got.append((DCF, it, deff / DCF, conv))
+    assert got == want["stages"]
+    assert np.array_equal(x, want["field"])
