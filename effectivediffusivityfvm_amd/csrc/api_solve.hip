@@ -145,11 +145,15 @@ static int wgl_resident_blocks(const deff_ctx *c, int R, bool fma, bool guard, i
     return DEFF_OK;
 }
 
-// link-symmetric 12-wave tiles (kernels_wgtile.hpp, k_sweep_wgsym): T = 8, R in WGS_ROWS
-#define WGS_DISPATCH(R_, F_, CALL)                                                              \
+// link-symmetric 12-wave tiles (kernels_wgtile.hpp, k_sweep_wgsym): T = 8 or 6, R in WGS_ROWS
+#define WGS_DISPATCH_T(T_, R_, F_, CALL)                                                        \
     do {                                                                                       \
-        if ((R_) == 4) { if (F_) { CALL(8, 4, true); } else { CALL(8, 4, false); } }            \
-        else { if (F_) { CALL(8, 5, true); } else { CALL(8, 5, false); } }                      \
+        if ((R_) == 4) { if (F_) { CALL(T_, 4, true); } else { CALL(T_, 4, false); } }          \
+        else { if (F_) { CALL(T_, 5, true); } else { CALL(T_, 5, false); } }                    \
+    } while (0)
+#define WGS_DISPATCH(T_, R_, F_, CALL)                                                          \
+    do {                                                                                       \
+        if ((T_) == 6) WGS_DISPATCH_T(6, R_, F_, CALL); else WGS_DISPATCH_T(8, R_, F_, CALL);   \
     } while (0)
 // (R = 6 -- 72-row tiles, images up to ~1230^2 -- needs 168 VGPRs + ~100 B of scratch, which lands in the halo exchange: 1152^2
 // 652 G against 704 G on tall tiles: not instantiated;
@@ -164,24 +168,24 @@ static int wgs_occ(int *per_cu)
     return DEFF_OK;
 }
 
-static int wgs_resident_blocks(const deff_ctx *c, int R, bool fma, int *resident)
+static int wgs_resident_blocks(const deff_ctx *c, int T, int R, bool fma, int *resident)
 {
     static std::mutex mu;
-    static int cache[64][8][2];
-    const int d = c->device;
+    static int cache[64][8][2][2];
+    const int d = c->device, t6 = T == 6 ? 1 : 0;
     if (d >= 0 && d < 64 && R >= 0 && R < 8) {
         std::lock_guard<std::mutex> lock(mu);
-        if (cache[d][R][fma] > 0) { *resident = cache[d][R][fma]; return DEFF_OK; }
+        if (cache[d][R][fma][t6] > 0) { *resident = cache[d][R][fma][t6]; return DEFF_OK; }
     }
     int per_cu = 0, cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
 #define OCC_CALL(T_, R_, C_) TRY((wgs_occ<T_, R_, C_>(&per_cu)))
-    WGS_DISPATCH(R, fma, OCC_CALL);
+    WGS_DISPATCH(T, R, fma, OCC_CALL);
 #undef OCC_CALL
     *resident = per_cu * cus;
     if (d >= 0 && d < 64 && R >= 0 && R < 8 && *resident > 0) {
         std::lock_guard<std::mutex> lock(mu);
-        cache[d][R][fma] = *resident;
+        cache[d][R][fma][t6] = *resident;
     }
     return DEFF_OK;
 }
@@ -604,7 +608,7 @@ static int plan_tall(deff_ctx *c, SweepPlan *pl, int T, int own_h, int R)
 static int choose_sym_R(deff_ctx *c, const SweepPlan *pl, int T, int own_h, int *sym_R)
 {
     *sym_R = 0;
-    if (T != 8 || !resident_allowed(c, pl) || c->lut_guard || c->tb_sym == 2) return DEFF_OK;
+    if ((T != 8 && T != 6) || !resident_allowed(c, pl) || c->lut_guard || c->tb_sym == 2) return DEFF_OK;
     if (c->tb_NW != 0 && c->tb_NW != WGS_WAVES) return DEFF_OK;
     if (c->tb_NW != WGS_WAVES && (c->tb_R != 0 || c->tb_LY != 0)) return DEFF_OK;
     int found = 0;
@@ -616,7 +620,7 @@ static int choose_sym_R(deff_ctx *c, const SweepPlan *pl, int T, int own_h, int 
         if (LY < T && cpi > 1) continue;                            // a tile's halo must end inside its immediate neighbours
         const long tiles = (long)pl->ntx * cpi * c->nimg;
         int res = 0;
-        TRY(wgs_resident_blocks(c, R, pl->fma, &res));
+        TRY(wgs_resident_blocks(c, T, R, pl->fma, &res));
         if (((tiles + 7) / 8) * 8 <= res) { found = R; break; }
     }
     if (!found) return DEFF_OK;
@@ -719,8 +723,9 @@ static int plan_blocked_pass(deff_ctx *c, SweepPlan *pl)
     int want_impl = c->tb_impl ? c->tb_impl : default_tb_impl(c);
     // a context just above the 4 Mi cells where the streaming form takes over still runs faster on tall tiles when they fit
     if (!c->tb_impl && want_impl == 1 && tall_R) want_impl = 2;
-    // workgroup tiles exist for T = 4 and 8; slabs' T = 1 remainder passes and the other T stay on the streaming kernel
-    if (want_impl == 2 && (T == 4 || T == 8) && !pl->T_override) {
+    // workgroup tiles exist for T = 4 and 8 (the 12-wave link-symmetric form also for T = 6, on request); slabs' T = 1 remainder
+    // passes and the other T stay on the streaming kernel
+    if (want_impl == 2 && (T == 4 || T == 8 || (T == 6 && c->tb_NW == WGS_WAVES)) && !pl->T_override) {
         // images that are ONE tall tile each (a stack of 128^2 images) recompute nothing and wait for nobody: nothing beats that
         const bool tall_whole = tall_R && pl->ntx == 1 && wgl_row_tiles(own_h, tall_R, T) == 1;
         if (!tall_whole) TRY(choose_sym_R(c, pl, T, own_h, &sym_R));
@@ -742,9 +747,24 @@ static int plan_blocked_pass(deff_ctx *c, SweepPlan *pl)
             if (take_sym) TRY(plan_sym(c, pl, T, own_h, sym_R));
             planned = true;
         }
+        if (!planned && T == 6) return fail(DEFF_EINVAL, "tb_T = 6 on 12-wave tiles: the tiles are not co-resident or the system is not link-symmetric");
         if (!planned) {
             TRY(plan_tiles8(c, pl, T, own_h));
-            if (tall_R && (!pl->resident || c->tb_NW == WGL_WAVES)) TRY(plan_tall(c, pl, T, own_h, tall_R));
+            // Images a little too large for the 12-wave tiles at T = 8 (1101 ... 1172 columns: 1152^2 is 297 tiles of 44 x 112
+            // owned cells) fit with passes of SIX sweeps -- 48 x 116 owned cells per tile, 240 tiles at 1152^2 -- and a sweep
+            // then costs (6 x 5 rows x 3 waves x ~142 clocks + the exchange) / 6 = ~3 300 clocks against ~4 000 ... 4 800 on
+            // tall tiles (lookups in every sweep, 4 waves per SIMD): taken whenever it fits and the caller has fixed neither T
+            // nor the form.
+            bool six = false;
+            if (!pl->resident && T == 8 && !c->tb_T && (c->tb_NW == 0 || c->tb_NW == WGS_WAVES) && !c->tb_R && !c->tb_LY) {
+                SweepPlan alt = *pl;
+                alt.T = 6;
+                plan_strips(c, 6, &alt);
+                int r6 = 0;
+                TRY(choose_sym_R(c, &alt, 6, own_h, &r6));
+                if (r6) { TRY(plan_sym(c, &alt, 6, own_h, r6)); *pl = alt; six = true; }
+            }
+            if (!six && tall_R && (!pl->resident || c->tb_NW == WGL_WAVES)) TRY(plan_tall(c, pl, T, own_h, tall_R));
         }
     } else {
         TRY(plan_streaming(c, pl, T, own_lo, own_h));
@@ -914,7 +934,7 @@ static int launch_resident_passes(deff_ctx *c, const SweepPlan &pl, int64_t *n)
         hipError_t e = hipSuccess;
         if (pl.NW == WGS_WAVES) {
 #define LAUNCH_WGS(T_, R_, C_) e = launch_wgsym<T_, R_, C_>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch)
-            WGS_DISPATCH(pl.R, pl.fma, LAUNCH_WGS);
+            WGS_DISPATCH(pl.T, pl.R, pl.fma, LAUNCH_WGS);
 #undef LAUNCH_WGS
         } else if (pl.NW == WGL_WAVES) {
             // (the symmetric short-cut exists in the unguarded kernels only: the guarded one branches on every link anyway)
@@ -1383,7 +1403,7 @@ try {
         int k = 0;
         *sweeps_per_pass = 1;
         if (resolve_kernel(c, &k) == DEFF_OK && k == DEFF_KERNEL_MATFREE_TB) {
-            *sweeps_per_pass = clamp_tb_T(c->tb_T ? c->tb_T : default_tb_T(c));
+            *sweeps_per_pass = c->plan_T ? c->plan_T : clamp_tb_T(c->tb_T ? c->tb_T : default_tb_T(c));   // (the planner may take T = 6)
         }
     }
     return DEFF_OK;

@@ -385,12 +385,12 @@ def test_resident_passes_with_a_second_context_loading_the_gpu(pkg):
     assert got == [ref] * 3
 
 
-@pytest.mark.parametrize("n,want_nw", [(1024, 12), (640, 8), (1536, 16), (2048, 16)])
+@pytest.mark.parametrize("n,want_nw", [(1024, 12), (640, 8), (1152, 12), (1536, 16), (2048, 16)])
 def test_long_solve_resident_equals_one_launch_per_pass(pkg, n, want_nw):
     """short parity tests do not catch exchange races (round 3's mailbox variant passed all of them and got
     one 150 001-sweep solve wrong), so the suite itself holds long ones: 150 001 sweeps through the solve loop (16 checks,
-    ~18 750 flag-synchronised passes per tile) on each resident form -- 12-wave link-symmetric tiles (1024^2), 8-wave tiles
-    (640^2), tall 16-wave tiles (1536^2, 2048^2) -- must give the SHA-256 of the field, the Deff and the last change of one
+    ~18 750 flag-synchronised passes per tile) on each resident form -- 12-wave link-symmetric tiles (1024^2; 1152^2 with passes
+    of six sweeps), 8-wave tiles (640^2), tall 16-wave tiles (1536^2, 2048^2) -- must give the SHA-256 of the field, the Deff and the last change of one
     launch per pass."""
     import hashlib
 
@@ -741,6 +741,69 @@ def test_sym_tiles_vs_oracle(pkg, oracle, shape, R):
         assert_field(s.get_field(), want1)
         s.sweeps(16)
         assert_field(s.get_field(), want2)
+
+
+@pytest.mark.parametrize("R", [4, 5])
+@pytest.mark.parametrize("shape", [(300, 200), (1030, 137), (250, 333), (2, 64), (97, 241), (1001, 333), (1152, 300)])
+def test_sym_tiles_with_passes_of_six_sweeps_vs_oracle(pkg, oracle, shape, R):
+    """k_sweep_wgsym<6, R> (round 4): the same tiles with passes of SIX sweeps -- halo of 6, 116 owned columns, 12R - 12 owned
+    rows -- which is what lets images of 1101 ... 1172 columns stay on coefficient-resident tiles.  Ragged strips and row tiles, odd
+    widths, a two-cell-wide image; 45 = 7 passes + 3 single sweeps, then 13 = 2 passes + 1; omega 2/3 and 1, both arithmetics."""
+    nx, ny = shape
+    rng = np.random.default_rng(nx * 11 + ny * 5 + R)
+    pix = rand_mask(rng, nx, ny, 0.5)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-3)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    x0 = rng.random((ny, nx))
+    for omega, kern, flavour, fma in ((2.0 / 3.0, 0, None, 0), (1.0, 1, None, 0), (2.0 / 3.0, 0, "fma", 1)):
+        want1 = oracle.sweeps(A, b, x0, 45, kernel=kern, omega=omega, flavour=flavour)
+        want2 = oracle.sweeps(A, b, want1, 13, kernel=kern, omega=omega, flavour=flavour)
+        with pkg.Solver(nx, ny, kernel="matfree_tb") as s:
+            s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 12); s.set_tuning("tb_R", R); s.set_tuning("tb_T", 6); s.set_tuning("fma", fma)
+            s.set_image(pix)
+            s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            s.set_field(x0)
+            s.sweeps(45, omega)
+            p = s.plan()
+            assert (p["tb_impl"], p["tb_NW"], p["tb_R"], p["tb_T"], p["tb_resident"], p["tb_sym"]) == (2, 12, R, 6, 1, 1), p
+            assert 1 <= p["tb_LY"] <= 12 * R - 12 and p["tb_LY"] * p["tb_chunks_per_image"] >= ny
+            assert s.last_launches() == (1 + 3, 6)
+            assert np.array_equal(s.get_field(), want1)
+            s.sweeps(13, omega)
+            assert np.array_equal(s.get_field(), want2)
+
+
+def test_planner_takes_passes_of_six_where_eight_do_not_fit(pkg, oracle):
+    """1152^2 -- 9 x 128 columns, the worst point of round 3's size curve (648-672 G on tall tiles) -- is 27 x 11 = 297 tiles of the
+    12-wave form at T = 8 and 24 x 10 = 240 at T = 6: the planner takes the latter on its own, a solve's 10 000-sweep intervals
+    are 1 666 passes + 4 single sweeps, and the results are the oracle's; a size that fits at T = 8 keeps T = 8."""
+    n = 1152
+    pix = oracle.synth_mask(n, n, 5, 0)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-3)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    it, deff, conv, want, _, _ = oracle.jacobi(A, b, oracle.linear_guess(n, n, 0.0, 1.0), D, 0.0, 1.0, 1e-9, 221, check_every=100)
+    with pkg.Solver(n, n) as s:
+        s.set_image(pix)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        r = s.solve(1e-9, 221, check_every=100)
+        p = s.plan()
+        assert (p["tb_impl"], p["tb_NW"], p["tb_R"], p["tb_T"], p["tb_resident"]) == (2, 12, 5, 6, 1), p
+        assert p["tb_strips"] * p["tb_chunks_per_image"] == 240
+        assert (r.iters, r.deff_raw, r.conv) == (it, deff, conv)
+        assert np.array_equal(s.get_field(), want)
+    with pkg.Solver(1024, 1024) as s:
+        s.synth_image(1, 0)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(16)
+        assert (s.plan()["tb_T"], s.plan()["tb_NW"], s.plan()["tb_R"]) == (8, 12, 5)
+    with pkg.Solver(1280, 1280) as s:                                  # too large for either: tall tiles, T = 8
+        s.synth_image(1, 0)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(16)
+        assert (s.plan()["tb_T"], s.plan()["tb_NW"]) == (8, 16)
 
 
 @pytest.mark.parametrize("R", [4, 5])
