@@ -1367,13 +1367,15 @@ try {
     TRY(consolidate(c));
     // streaming form: 2 stamps per wave tile; workgroup-tile form: T + 4 per tile, flattened -- *ntiles is always
     // the number of PAIRS the buffer must hold
-    const int n = pl.impl == 2 ? (pl.ntx * pl.tgy * (pl.T + 4) + 1) / 2 : pl.ntx * pl.tgy;
+    // (resident launches stamp 12 clocks per tile whatever T: entry + 3 passes x {neighbours seen, halo in, swept, published})
+    const bool res_stamps = pl.impl == 2 && pl.resident;
+    const int n = res_stamps ? (pl.ntx * pl.tgy * 12 + 1) / 2 : pl.impl == 2 ? (pl.ntx * pl.tgy * (pl.T + 4) + 1) / 2 : pl.ntx * pl.tgy;
     *ntiles = n;
     if (!out) return DEFF_OK;
     HIP_TRY(hipMalloc((void **)&c->tb_stamps, sizeof(unsigned long long) * 2 * n));
     HIP_TRY(hipMemsetAsync(c->tb_stamps, 0, sizeof(unsigned long long) * 2 * n, c->stream));
     int rc = DEFF_OK;
-    if (pl.impl == 2 && pl.resident && pl.T == 8) rc = enqueue_sweeps(c, pl, 3 * pl.T);   // k_sweep_wgres: 12 stamps per tile, 3 passes
+    if (res_stamps) rc = enqueue_sweeps(c, pl, 3 * pl.T);                                  // k_sweep_wgres / wgsym: 12 stamps per tile, 3 passes
     else rc = enqueue_tb_pass(c, pl);
     if (rc != DEFF_OK) { (void)hipFree(c->tb_stamps); c->tb_stamps = nullptr; return rc; }
     hipError_t e = hipMemcpyAsync(out, c->tb_stamps, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost, c->stream);

@@ -30,7 +30,7 @@ with pkg.Solver(n, n) as s:
     ms = min(s.sweeps(4800) for _ in range(3))
     p = s.plan()
     print(f"n={n} plan NW={p['tb_NW']} R={p['tb_R']} LY={p['tb_LY']} tiles={p['tb_strips']}x{p['tb_chunks_per_image']} resident={p['tb_resident']}: "
-          f"{ms / 600 * 1e3:.2f} us per pass of 8 sweeps = {n * n * 4800 / ms / 1e6:.0f} G cells*iter/s")
+          f"{ms / (4800 / p['tb_T']) * 1e3:.2f} us per pass of {p['tb_T']} sweeps = {n * n * 4800 / ms / 1e6:.0f} G cells*iter/s")
     if not p["tb_resident"]:
         sys.exit(0)
     L = _capi.load()
