@@ -145,7 +145,7 @@ static int wgl_resident_blocks(const deff_ctx *c, int R, bool fma, bool guard, i
     return DEFF_OK;
 }
 
-// link-symmetric 12-wave tiles (kernels_wgtile.hpp, k_sweep_wgsym): T = 8 or 6, R in WGS_ROWS
+// link-symmetric 12-wave tiles (kernels_wgtile.hpp, k_sweep_wgsym): T = 8, 6 or 4, R in WGS_ROWS
 #define WGS_DISPATCH_T(T_, R_, F_, CALL)                                                        \
     do {                                                                                       \
         if ((R_) == 4) { if (F_) { CALL(T_, 4, true); } else { CALL(T_, 4, false); } }          \
@@ -153,7 +153,9 @@ static int wgl_resident_blocks(const deff_ctx *c, int R, bool fma, bool guard, i
     } while (0)
 #define WGS_DISPATCH(T_, R_, F_, CALL)                                                          \
     do {                                                                                       \
-        if ((T_) == 6) WGS_DISPATCH_T(6, R_, F_, CALL); else WGS_DISPATCH_T(8, R_, F_, CALL);   \
+        if ((T_) == 6) WGS_DISPATCH_T(6, R_, F_, CALL);                                        \
+        else if ((T_) == 4) WGS_DISPATCH_T(4, R_, F_, CALL);                                   \
+        else WGS_DISPATCH_T(8, R_, F_, CALL);                                                  \
     } while (0)
 // (R = 6 -- 72-row tiles, images up to ~1230^2 -- needs 168 VGPRs + ~100 B of scratch, which lands in the halo exchange: 1152^2
 // 652 G against 704 G on tall tiles: not instantiated;
@@ -171,8 +173,8 @@ static int wgs_occ(int *per_cu)
 static int wgs_resident_blocks(const deff_ctx *c, int T, int R, bool fma, int *resident)
 {
     static std::mutex mu;
-    static int cache[64][8][2][2];
-    const int d = c->device, t6 = T == 6 ? 1 : 0;
+    static int cache[64][8][2][3];
+    const int d = c->device, t6 = T == 6 ? 1 : T == 4 ? 2 : 0;
     if (d >= 0 && d < 64 && R >= 0 && R < 8) {
         std::lock_guard<std::mutex> lock(mu);
         if (cache[d][R][fma][t6] > 0) { *resident = cache[d][R][fma][t6]; return DEFF_OK; }
@@ -608,8 +610,9 @@ static int plan_tall(deff_ctx *c, SweepPlan *pl, int T, int own_h, int R)
 static int choose_sym_R(deff_ctx *c, const SweepPlan *pl, int T, int own_h, int *sym_R)
 {
     *sym_R = 0;
-    if ((T != 8 && T != 6) || !resident_allowed(c, pl) || c->lut_guard || c->tb_sym == 2) return DEFF_OK;
+    if ((T != 8 && T != 6 && T != 4) || !resident_allowed(c, pl) || c->lut_guard || c->tb_sym == 2) return DEFF_OK;
     if (c->tb_NW != 0 && c->tb_NW != WGS_WAVES) return DEFF_OK;
+    if (T != 8 && c->tb_T && c->tb_NW != WGS_WAVES) return DEFF_OK;  // a caller's T = 4 / 6 means these tiles only together with tb_NW = 12
     if (c->tb_NW != WGS_WAVES && (c->tb_R != 0 || c->tb_LY != 0)) return DEFF_OK;
     int found = 0;
     for (int R : WGS_ROWS) {
@@ -726,6 +729,7 @@ static int plan_blocked_pass(deff_ctx *c, SweepPlan *pl)
     // workgroup tiles exist for T = 4 and 8 (the 12-wave link-symmetric form also for T = 6, on request); slabs' T = 1 remainder
     // passes and the other T stay on the streaming kernel
     if (want_impl == 2 && (T == 4 || T == 8 || (T == 6 && c->tb_NW == WGS_WAVES)) && !pl->T_override) {
+        const bool sym_only = c->tb_NW == WGS_WAVES && (T == 6 || T == 4) && c->tb_T;   // the caller asked for 12-wave tiles at this T
         // images that are ONE tall tile each (a stack of 128^2 images) recompute nothing and wait for nobody: nothing beats that
         const bool tall_whole = tall_R && pl->ntx == 1 && wgl_row_tiles(own_h, tall_R, T) == 1;
         if (!tall_whole) TRY(choose_sym_R(c, pl, T, own_h, &sym_R));
@@ -747,7 +751,7 @@ static int plan_blocked_pass(deff_ctx *c, SweepPlan *pl)
             if (take_sym) TRY(plan_sym(c, pl, T, own_h, sym_R));
             planned = true;
         }
-        if (!planned && T == 6) return fail(DEFF_EINVAL, "tb_T = 6 on 12-wave tiles: the tiles are not co-resident or the system is not link-symmetric");
+        if (!planned && sym_only) return fail(DEFF_EINVAL, "tb_T = %d on 12-wave tiles: the tiles are not co-resident or the system is not link-symmetric", T);
         if (!planned) {
             TRY(plan_tiles8(c, pl, T, own_h));
             // Images a little too large for the 12-wave tiles at T = 8 (1101 ... 1172 columns: 1152^2 is 297 tiles of 44 x 112
@@ -755,16 +759,21 @@ static int plan_blocked_pass(deff_ctx *c, SweepPlan *pl)
             // then costs (6 x 5 rows x 3 waves x ~142 clocks + the exchange) / 6 = ~3 300 clocks against ~4 000 ... 4 800 on
             // tall tiles (lookups in every sweep, 4 waves per SIMD): taken whenever it fits and the caller has fixed neither T
             // nor the form.
-            bool six = false;
+            // Passes of FOUR (52 x 120 owned cells: up to 1208 columns x 1248 rows) come after that: ~4 200 clocks per sweep,
+            // still ahead of the tall tiles' ~4 900 where those need R = 5.
+            bool shorter = false;
             if (!pl->resident && T == 8 && !c->tb_T && (c->tb_NW == 0 || c->tb_NW == WGS_WAVES) && !c->tb_R && !c->tb_LY) {
-                SweepPlan alt = *pl;
-                alt.T = 6;
-                plan_strips(c, 6, &alt);
-                int r6 = 0;
-                TRY(choose_sym_R(c, &alt, 6, own_h, &r6));
-                if (r6) { TRY(plan_sym(c, &alt, 6, own_h, r6)); *pl = alt; six = true; }
+                for (int Ts : {6, 4}) {
+                    SweepPlan alt = *pl;
+                    alt.T = Ts;
+                    plan_strips(c, Ts, &alt);
+                    int rs = 0;
+                    TRY(choose_sym_R(c, &alt, Ts, own_h, &rs));
+                    if (Ts == 4 && rs && rs < 5 && tall_R && tall_R <= 4) rs = 0;      // (4 x 4 rows per sweep: no better than tall R = 4)
+                    if (rs) { TRY(plan_sym(c, &alt, Ts, own_h, rs)); *pl = alt; shorter = true; break; }
+                }
             }
-            if (!six && tall_R && (!pl->resident || c->tb_NW == WGL_WAVES)) TRY(plan_tall(c, pl, T, own_h, tall_R));
+            if (!shorter && tall_R && (!pl->resident || c->tb_NW == WGL_WAVES)) TRY(plan_tall(c, pl, T, own_h, tall_R));
         }
     } else {
         TRY(plan_streaming(c, pl, T, own_lo, own_h));

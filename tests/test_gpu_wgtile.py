@@ -743,12 +743,14 @@ def test_sym_tiles_vs_oracle(pkg, oracle, shape, R):
         assert_field(s.get_field(), want2)
 
 
+@pytest.mark.parametrize("T", [6, 4])
 @pytest.mark.parametrize("R", [4, 5])
-@pytest.mark.parametrize("shape", [(300, 200), (1030, 137), (250, 333), (2, 64), (97, 241), (1001, 333), (1152, 300)])
-def test_sym_tiles_with_passes_of_six_sweeps_vs_oracle(pkg, oracle, shape, R):
-    """k_sweep_wgsym<6, R> (round 4): the same tiles with passes of SIX sweeps -- halo of 6, 116 owned columns, 12R - 12 owned
-    rows -- which is what lets images of 1101 ... 1172 columns stay on coefficient-resident tiles.  Ragged strips and row tiles, odd
-    widths, a two-cell-wide image; 45 = 7 passes + 3 single sweeps, then 13 = 2 passes + 1; omega 2/3 and 1, both arithmetics."""
+@pytest.mark.parametrize("shape", [(300, 200), (1030, 137), (250, 333), (2, 64), (97, 241), (1001, 333), (1152, 300), (1208, 150)])
+def test_sym_tiles_with_passes_of_six_and_four_sweeps_vs_oracle(pkg, oracle, shape, R, T):
+    """k_sweep_wgsym<6, R> and <4, R> (round 4): the same tiles with passes of SIX (FOUR) sweeps -- halo of 6 (4), 116 (120) owned
+    columns, 12R - 12 (12R - 8) owned rows -- which is what lets images of 1101 ... 1172 (1208) columns stay on coefficient-resident
+    tiles.  Ragged strips and row tiles, odd widths, a two-cell-wide image; 45 = 7 passes + 3 single sweeps (11 + 1), then
+    13 = 2 passes + 1 (3 + 1); omega 2/3 and 1, both arithmetics."""
     nx, ny = shape
     rng = np.random.default_rng(nx * 11 + ny * 5 + R)
     pix = rand_mask(rng, nx, ny, 0.5)
@@ -759,15 +761,16 @@ def test_sym_tiles_with_passes_of_six_sweeps_vs_oracle(pkg, oracle, shape, R):
         want1 = oracle.sweeps(A, b, x0, 45, kernel=kern, omega=omega, flavour=flavour)
         want2 = oracle.sweeps(A, b, want1, 13, kernel=kern, omega=omega, flavour=flavour)
         with pkg.Solver(nx, ny, kernel="matfree_tb") as s:
-            s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 12); s.set_tuning("tb_R", R); s.set_tuning("tb_T", 6); s.set_tuning("fma", fma)
+            s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 12); s.set_tuning("tb_R", R); s.set_tuning("tb_T", T); s.set_tuning("fma", fma)
             s.set_image(pix)
             s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
             s.set_field(x0)
             s.sweeps(45, omega)
             p = s.plan()
-            assert (p["tb_impl"], p["tb_NW"], p["tb_R"], p["tb_T"], p["tb_resident"], p["tb_sym"]) == (2, 12, R, 6, 1, 1), p
-            assert 1 <= p["tb_LY"] <= 12 * R - 12 and p["tb_LY"] * p["tb_chunks_per_image"] >= ny
-            assert s.last_launches() == (1 + 3, 6)
+            assert (p["tb_impl"], p["tb_NW"], p["tb_R"], p["tb_T"], p["tb_resident"], p["tb_sym"]) == (2, 12, R, T, 1, 1), p
+            assert 1 <= p["tb_LY"] <= 12 * R - 2 * T and p["tb_LY"] * p["tb_chunks_per_image"] >= ny
+            assert p["tb_strips"] == (1 if nx <= 128 else 2 + (nx - 128 - 1) // (128 - 2 * T))
+            assert s.last_launches() == (1 + 45 % T, T)
             assert np.array_equal(s.get_field(), want1)
             s.sweeps(13, omega)
             assert np.array_equal(s.get_field(), want2)
@@ -798,7 +801,24 @@ def test_planner_takes_passes_of_six_where_eight_do_not_fit(pkg, oracle):
         s.init_linear(0.0, 1.0)
         s.sweeps(16)
         assert (s.plan()["tb_T"], s.plan()["tb_NW"], s.plan()["tb_R"]) == (8, 12, 5)
-    with pkg.Solver(1280, 1280) as s:                                  # too large for either: tall tiles, T = 8
+    # 1200 columns: 11 strips at T = 6 need 128 + 10 x 116 = 1288 >= 1200 -> 11 strips x 25 row tiles = 275: no; T = 4: 10 strips
+    # (128 + 9 x 120 = 1208) x ceil(1200 / 52) = 24 -> 240 tiles of 4 + 5 x 12 - 8 rows
+    n = 1200
+    pix = oracle.synth_mask(n, n, 6, 0)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-3)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    it, deff, conv, want, _, _ = oracle.jacobi(A, b, oracle.linear_guess(n, n, 0.0, 1.0), D, 0.0, 1.0, 1e-9, 203, check_every=100)
+    with pkg.Solver(n, n) as s:
+        s.set_image(pix)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        r = s.solve(1e-9, 203, check_every=100)
+        p = s.plan()
+        assert (p["tb_impl"], p["tb_NW"], p["tb_R"], p["tb_T"], p["tb_resident"]) == (2, 12, 5, 4, 1), p
+        assert p["tb_strips"] * p["tb_chunks_per_image"] == 240
+        assert (r.iters, r.deff_raw, r.conv) == (it, deff, conv)
+        assert np.array_equal(s.get_field(), want)
+    with pkg.Solver(1280, 1280) as s:                                  # too large for all three: tall tiles, T = 8
         s.synth_image(1, 0)
         s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
         s.init_linear(0.0, 1.0)
