@@ -385,12 +385,12 @@ def test_resident_passes_with_a_second_context_loading_the_gpu(pkg):
     assert got == [ref] * 3
 
 
-@pytest.mark.parametrize("n,want_nw", [(1024, 12), (640, 8), (1152, 12), (1536, 16), (2048, 16)])
+@pytest.mark.parametrize("n,want_nw", [(1024, 12), (640, 8), (1152, 12), (1200, 12), (1536, 16), (2048, 16)])
 def test_long_solve_resident_equals_one_launch_per_pass(pkg, n, want_nw):
     """short parity tests do not catch exchange races (round 3's mailbox variant passed all of them and got
     one 150 001-sweep solve wrong), so the suite itself holds long ones: 150 001 sweeps through the solve loop (16 checks,
     ~18 750 flag-synchronised passes per tile) on each resident form -- 12-wave link-symmetric tiles (1024^2; 1152^2 with passes
-    of six sweeps), 8-wave tiles (640^2), tall 16-wave tiles (1536^2, 2048^2) -- must give the SHA-256 of the field, the Deff and the last change of one
+    of six sweeps, 1200^2 with passes of four), 8-wave tiles (640^2), tall 16-wave tiles (1536^2, 2048^2) -- must give the SHA-256 of the field, the Deff and the last change of one
     launch per pass."""
     import hashlib
 
@@ -824,6 +824,66 @@ def test_planner_takes_passes_of_six_where_eight_do_not_fit(pkg, oracle):
         s.init_linear(0.0, 1.0)
         s.sweeps(16)
         assert (s.plan()["tb_T"], s.plan()["tb_NW"]) == (8, 16)
+
+
+def test_shorter_passes_on_a_stack_and_on_a_dictionary_system(pkg, oracle):
+    """The planner's fall-back to passes of six / four sweeps beyond one 2-phase image: a STACK of two 1160 x 560 images (286 tiles
+    at T = 8, 240 at T = 6) whose images stop at different checks, and a three-class system (rows from the harvested
+    dictionary, checked link-symmetric) of 1190^2 (308 / 275 tiles at T = 8 / 6, 230 at T = 4); with impermeable solid the same
+    image is not bit-symmetric and stays on tall tiles."""
+    nx, ny, B = 1160, 560, 2
+    rng = np.random.default_rng(77)
+    pixs = [rand_mask(rng, nx, ny, 0.4 + 0.2 * k) for k in range(B)]
+    with pkg.Solver(nx, ny, nimg=B) as s:
+        s.set_image(np.stack(pixs))
+        s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        res = s.solve(1e-2, 900, check_every=100)
+        got = s.get_field()
+        p = s.plan()
+        assert (p["tb_impl"], p["tb_NW"], p["tb_R"], p["tb_T"], p["tb_resident"]) == (2, 12, 5, 6, 1), p
+        assert p["tb_strips"] * p["tb_chunks_per_image"] * B == 240
+    iters = set()
+    for k in range(B):
+        D = oracle.fill_D_2phase(pixs[k], 1.0, 1e-2)
+        A, b = oracle.discretize(D, 0.0, 1.0)
+        it, deff, conv, x, _, _ = oracle.jacobi(A, b, oracle.linear_guess(nx, ny, 0.0, 1.0), D, 0.0, 1.0, 1e-2, 900, check_every=100)
+        assert (res[k].iters, res[k].deff_raw, res[k].conv) == (it, deff, conv)
+        assert np.array_equal(got[k * ny:(k + 1) * ny], x)
+        iters.add(it)
+    assert len(iters) > 1
+    n = 1190
+    pix = np.where(rng.random((n, n)) < 0.3, 255, np.where(rng.random((n, n)) < 0.5, 120, 0)).astype(np.uint8)
+    pix[0, :] = 255                                                    # solid top and bottom rows: no pore cell reaches across the wrap
+    pix[-1, :] = 255
+    # three classes with a permeable solid: DiscretizeMatrix2D on a three-valued D plane, rows harvested into the dictionary
+    D3 = oracle.fill_D_3phase(pix, 1.0, 0.5, 30.0)
+    A3, b3 = oracle.discretize(D3, 0.0, 1.0)
+    want3 = oracle.sweeps(A3, b3, oracle.linear_guess(n, n, 0.0, 1.0), 23)
+    with pkg.Solver(n, n) as s:
+        s.set_image(pix)
+        s.assemble_3phase(0.5, 1.0, 30.0, 0.0, 1.0, None)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(23)
+        p = s.plan()
+        assert s.kernel_in_use() == "matfree_tb"
+        assert (p["tb_impl"], p["tb_NW"], p["tb_R"], p["tb_T"], p["tb_resident"], p["tb_sym"]) == (2, 12, 5, 4, 1, 1), p
+        assert np.array_equal(s.get_field(), want3)
+    # impermeable solid: identity rows carry +0 links where their neighbours carry -0 -- not bit-symmetric, so the planner must
+    # keep such a system off the link-symmetric tiles (tall tiles, looked-up rows)
+    grid, _ = oracle.floodfill((pix > 200).astype(np.uint32))
+    D3 = oracle.fill_D_3phase(pix, 1.0, 0.0, 30.0)
+    with np.errstate(all="ignore"):
+        A3, b3 = oracle.discretize(D3, 0.0, 1.0, grid=grid)
+        want3 = oracle.sweeps(A3, b3, oracle.linear_guess(n, n, 0.0, 1.0), 23)
+    with pkg.Solver(n, n) as s:
+        s.set_image(pix)
+        s.assemble_3phase(0.0, 1.0, 30.0, 0.0, 1.0, grid)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(23)
+        p = s.plan()
+        assert (p["tb_impl"], p["tb_NW"], p["tb_T"], p["tb_resident"], p["tb_sym"]) == (2, 16, 8, 1, 2), p
+        assert_field(s.get_field(), want3)
 
 
 @pytest.mark.parametrize("R", [4, 5])
