@@ -98,3 +98,23 @@ def test_share_gpu_with_rccl_is_refused_by_the_ranks():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--share-gpu", "--steps", "1"], env=_env(), capture_output=True,
                        text=True, timeout=600)
     assert r.returncode != 0 and "--share-gpu needs --transport host" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["images", "slab"])
+def test_one_rank_under_the_drivers_launcher_with_rccl(mode):
+    """The one RCCL path a one-GPU box can execute: the driver's own form, `python -m torch.distributed.run --nproc-per-node 1
+    ... bench.py --gpus 1`, brings up the 'nccl' (= RCCL) process group on the device, and the barrier and the gather of the
+    ranks' times that bracket the timed region go through it."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "1", "--mode", mode, "--size", "1024", "--steps", "2",
+                        "--warmup", "1", "--sweeps-per-step", "64", "--primary-only"], env=_env(), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and len(out["per_rank_ms_per_step"]) == 1
+    assert abs(out["value"] - 1024.0 * 1024.0 * 64 / (out["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * out["value"]
