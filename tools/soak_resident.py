@@ -35,7 +35,7 @@ for n in [int(a) for a in args] or [1024, 1536, 2048]:
             dt = time.perf_counter() - t0
             p = s.plan()
             out[tag] = {"sha256": hashlib.sha256(s.get_field().tobytes()).hexdigest(), "seconds": round(dt, 2),
-                        "G_cells_iter_per_s": round(n * n * sweeps / dt / 1e9, 1), "NW": p["tb_NW"], "R": p["tb_R"],
+                        "G_cells_iter_per_s": round(n * n * sweeps / dt / 1e9, 1), "NW": p["tb_NW"], "R": p["tb_R"], "T": p["tb_T"],
                         "resident": p["tb_resident"], "fallbacks": s.plan_value("tb_fallbacks")}
     out["equal"] = out["resident"]["sha256"] == out["one_launch_per_pass"]["sha256"]
     ok = ok and out["equal"] and out["resident"]["fallbacks"] == 0
