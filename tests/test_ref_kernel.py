@@ -72,6 +72,24 @@ def test_hip_sweeps_equal_the_references_kernels(pkg, oracle, img00000, kernel, 
         assert np.array_equal(got, want), (kernel, tune, which, rel_l2(got, want))
 
 
+@pytest.mark.parametrize("n,form", [(1152, (12, 6)), (1200, (12, 4)), (1536, (16, 8))])
+def test_mid_size_default_plans_equal_the_references_kernel(pkg, oracle, n, form, tmp_path):
+    """The resident forms the planner picks between 1100^2 and 2300^2 -- 12-wave link-symmetric tiles with passes of six and of
+    four sweeps, tall 16-wave tiles -- against 27 launches of the reference's updateX_SOR after the reference's own assembly."""
+    pix = oracle.synth_mask(n, n, 12345, 0)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-3)
+    A, b = ob.ref_discretize(D, 0.0, 1.0, tmpdir=tmp_path)
+    want = ob.ref_sweeps(A, b, oracle.linear_guess(n, n, 0.0, 1.0), 27, tmpdir=tmp_path)
+    with pkg.Solver(n, n) as s:
+        s.set_image(pix)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        s.sweeps(27)
+        p = s.plan()
+        assert (p["tb_NW"], p["tb_T"]) == form and p["tb_resident"] == 1, p
+        assert np.array_equal(s.get_field(), want)
+
+
 def test_hip_3phase_sweeps_equal_the_references_kernels(pkg, oracle, tmp_path):
     """Three pixel classes, impermeable solid (Ds = 0), the reference's own flood fill and ImpSolid assembly, the reference's
     kernel with its non-zero link test (cuh:77) against the library's harvested dictionary + guarded kernels."""
