@@ -127,6 +127,7 @@ try {
     if (c->mf_host) (void)hipHostFree(c->mf_host);
     if (c->q) (void)hipFree(c->q);
     if (c->resid) (void)hipFree(c->resid);
+    if (c->tb_dealt) (void)hipFree(c->tb_dealt);
     if (c->res_flags) (void)hipFree(c->res_flags);
     if (c->res_abort) (void)hipFree(c->res_abort);
     if (c->res_backup) (void)hipFree(c->res_backup);
@@ -269,6 +270,11 @@ try {
     else if (!strcmp(key, "fma")) c->fma = value ? 1 : 0;
     else if (!strcmp(key, "tb_wall_halo")) c->tb_wall_halo = value > 2 ? 2 : value;
     else if (!strcmp(key, "tb_wg")) c->tb_wg = (value + 7) / 8 * 8;
+    else if (!strcmp(key, "tb_ranked")) c->tb_ranked = value ? 1 : 0;
+    else if (!strcmp(key, "tb_rank_w0")) c->tb_rank_w[0] = value;
+    else if (!strcmp(key, "tb_rank_w1")) c->tb_rank_w[1] = value;
+    else if (!strcmp(key, "tb_rank_w2")) c->tb_rank_w[2] = value;
+    else if (!strcmp(key, "tb_rank_wall")) c->tb_rank_wall = value;
     else return fail(DEFF_EINVAL, "unknown tuning key '%s'", key);
     return DEFF_OK;
 }
@@ -289,6 +295,7 @@ try {
     else if (!strcmp(key, "tb_sym")) *value = c->links_sym;
     else if (!strcmp(key, "tb_NW")) *value = c->plan_NW;
     else if (!strcmp(key, "tb_fallbacks")) *value = c->res_fallbacks;
+    else if (!strcmp(key, "tb_ranked")) *value = c->plan_ranked;
     else return fail(DEFF_EINVAL, "unknown plan key '%s'", key);
     return DEFF_OK;
 }

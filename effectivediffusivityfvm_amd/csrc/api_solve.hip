@@ -658,6 +658,147 @@ static int plan_sym(deff_ctx *c, SweepPlan *pl, int T, int own_h, int R)
 // chunks per image minimising rounds x tile cost; for k rounds only the largest chunk count that fits matters.  (Stacks of
 // small images: 3 072 x 128^2 as whole-image tiles 1 266 G cells*iter/s against 1 107 G for the 4 x 32-row tiles a
 // halo-blind model picks.)
+// Chunk heights by service order.  A SIMD serves the waves it holds oldest first (tools/tb_stamps.py: with equal chunks the
+// three waves of a SIMD end at 71 / 89 / 108 us of a 4096^2 pass -- the SIMD runs on two waves, then on one, for a third of the
+// launch), and which wave is the oldest is known beforehand: workgroups go to the XCDs round-robin and fill an XCD's CUs
+// once around before any CU gets its second one (observed on every SIMD of the chip: workgroup (blockIdx >> 3) / 32 of an XCD
+// = wave slot 0, 1, 2).  So the chunks need not be equal: the oldest rank gets the tallest, the youngest the shortest, in
+// proportion to the speeds the ranks run at (tb_rank_w), and all three end together.  Each strip is cut into nq chunks
+// per rank -- the oldest rank's at the top, the youngest's at the bottom --, a workgroup's four waves hold four stacked
+// chunks of one rank, and an XCD's workgroups hold neighbouring strips (its L2 sees the shared halo rows).  The result
+// is written as a table the kernel reads (k_sweep_matfree_tb, `dealt`); every row is still covered once, so the bits
+// cannot change -- if the dispatch order is ever different (another process on the GPU), only the balance is lost.
+static int deal_ranked_tiles(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int own_h, int resident, bool *dealt)
+{
+    *dealt = false;
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    const int xcds = 8, per_xcd = cus / xcds, occ = cus > 0 ? resident / cus : 0;
+    if (cus % xcds != 0 || occ != 3 || resident != occ * cus) return DEFF_OK;       // three waves per SIMD is what was measured
+    const int slots = cus * 4;                                                       // waves per rank
+    const int ntx = pl->ntx, cap = own_h / (3 * T);
+    const int nq = std::min(slots / ntx, cap);
+    if (nq < 1 || c->tb_rank_wall < 1000 || c->tb_rank_w[0] < 1 || c->tb_rank_w[1] < 1 || c->tb_rank_w[2] < 1) return DEFF_OK;
+    const std::vector<int> key = {T, own_lo, own_h, ntx, pl->shift, resident, c->tb_rank_w[0], c->tb_rank_w[1], c->tb_rank_w[2], c->tb_rank_wall};
+    auto fill_plan = [&]() {
+        pl->dealt = c->tb_dealt;
+        pl->LY = c->tb_dealt_LY;
+        pl->tcpi = pl->tgy = 3 * c->tb_dealt_nmax;                                   // (the stamps' numbering: rank, strip, chunk < nmax)
+        pl->tgx = (ntx * pl->tgy + 3) / 4;
+        pl->tblocks = resident;
+        *dealt = true;
+    };
+    if (c->tb_dealt && key == c->tb_dealt_key) { fill_plan(); return DEFF_OK; }
+    const double v[3] = {(double)c->tb_rank_w[0], (double)c->tb_rank_w[1], (double)c->tb_rank_w[2]};
+    const int K = T * (T - 1) + 8;                        // level steps a chunk costs on top of T per row: halo triangles + fill
+    // A wall strip's waves look up b as well and run 10-15 % longer per row (mean end of a 4096^2 pass by strip, equal chunk
+    // counts: 107 us in the first strip against 94...100 in the others): its rows count tb_rank_wall per mille.  A last strip
+    // that is partly outside the mesh (4096 columns: half of it) moves fewer cache lines: the surcharge in proportion.
+    std::vector<double> weight(ntx, 1.0);
+    const bool walls = ntx >= 3;
+    if (walls) {
+        const int hw = (T + 1) & ~1, wout = TB_COLS - 2 * hw;
+        const int last_cols = c->nx - ((ntx - 1) * wout - pl->shift);                // columns of the last strip inside the mesh
+        weight[0] = c->tb_rank_wall / 1000.0;
+        weight[ntx - 1] = 1.0 + (c->tb_rank_wall / 1000.0 - 1.0) * std::min(last_cols, TB_COLS) / TB_COLS;
+    }
+    // chunks per strip and rank: nq each, then the wave slots left over go one by one to the strip that would end last
+    // (time of a strip = its level steps over the speed of its waves: w (T own_h + K sum n_r) / sum n_r v_r)
+    struct Strip { int n[3]; int ly[3]; };
+    std::vector<Strip> st(ntx);
+    for (auto &q : st) q.n[0] = q.n[1] = q.n[2] = nq;
+    int spare[3] = {slots - ntx * nq, slots - ntx * nq, slots - ntx * nq};
+    auto strip_time = [&](int tx) {
+        const Strip &q = st[tx];
+        return weight[tx] * ((double)T * own_h + (double)K * (q.n[0] + q.n[1] + q.n[2])) / (q.n[0] * v[0] + q.n[1] * v[1] + q.n[2] * v[2]);
+    };
+    for (int it = 0; it < 3 * slots; ++it) {
+        int worst = -1;
+        double tw = 0;
+        for (int tx = 0; tx < ntx; ++tx) {
+            const double t = strip_time(tx);
+            if (t > tw) { tw = t; worst = tx; }
+        }
+        int r = -1;
+        for (int k = 0; k < 3; ++k)
+            if (spare[k] > 0 && st[worst].n[k] < cap && (r < 0 || spare[k] > spare[r])) r = k;
+        if (r < 0) break;
+        ++st[worst].n[r];
+        --spare[r];
+    }
+    // chunk heights: a rank's chunk gets the rows its waves finish in the strip's time; the oldest rank takes the rounding
+    int nmax = 0;
+    for (int tx = 0; tx < ntx; ++tx) {
+        Strip &q = st[tx];
+        const double t = strip_time(tx) / weight[tx];
+        int left = own_h;
+        for (int r = 2; r >= 1; --r) {
+            int ly = (int)((t * v[r] - K) / T);
+            if (ly < T) ly = T;
+            q.ly[r] = ly;
+            left -= q.n[r] * ly;
+        }
+        q.ly[0] = (left + q.n[0] - 1) / q.n[0];
+        if (q.ly[0] < T) return DEFF_OK;
+        nmax = std::max(nmax, std::max(q.n[0], std::max(q.n[1], q.n[2])));
+    }
+    const size_t entries = (size_t)resident * 4;
+    {
+        std::vector<int4> &tab = c->tb_dealt_host;
+        tab.assign(entries, make_int4(0, 0, 0, 0));
+        const int own_hi = own_lo + own_h;
+        auto tile = [&](int r, int tx, int q) {
+            const Strip &sp = st[tx];
+            int ry0 = own_lo;
+            for (int k = 0; k < r; ++k) ry0 += sp.n[k] * sp.ly[k];
+            ry0 += q * sp.ly[r];
+            int rows_here = std::min(sp.ly[r], own_hi - ry0);
+            if (r == 2 && q == sp.n[2] - 1) rows_here = own_hi - ry0;              // the youngest rank's last chunk takes what rounding left over
+            return make_int4(tx, ry0, rows_here > 0 ? rows_here : 0, (r * ntx + tx) * nmax + q);
+        };
+        for (int r = 0; r < 3; ++r) {
+            // workgroup m of rank r: XCD m / per_xcd, the (m % per_xcd)-th of that XCD's workgroups of this rank
+            auto slot = [&](int m, int w) { return ((((size_t)(r * per_xcd + m % per_xcd) << 3) | (size_t)(m / per_xcd)) * 4 + w); };
+            std::vector<char> used((size_t)cus * 4, 0);
+            // the wall strips' chunks first, one per workgroup and spread over the chip (twelve waves looking up b on one CU
+            // were the last to end by 5 us), each rank starting elsewhere
+            std::vector<int4> wall_tiles;
+            if (walls)
+                for (int tx : {0, ntx - 1})
+                    for (int q = 0; q < st[tx].n[r]; ++q) wall_tiles.push_back(tile(r, tx, q));
+            const int nw = (int)wall_tiles.size();
+            for (int k = 0; k < nw; ++k) {
+                int m = (int)(((long)k * cus) / std::max(nw, 1) + (long)r * cus / 3) % cus, w = 0;
+                while (used[(size_t)m * 4 + w]) { if (++w == 4) { w = 0; m = (m + 1) % cus; } }
+                used[(size_t)m * 4 + w] = 1;
+                tab[slot(m, w)] = wall_tiles[k];
+            }
+            // the inner strips in order (chunk index fastest): a workgroup's waves hold stacked chunks, an XCD neighbouring strips
+            int m = 0, w = 0;
+            for (int tx = walls ? 1 : 0; tx < (walls ? ntx - 1 : ntx); ++tx)
+                for (int q = 0; q < st[tx].n[r]; ++q) {
+                    while (m < cus && used[(size_t)m * 4 + w]) { if (++w == 4) { w = 0; ++m; } }
+                    if (m >= cus) return fail(DEFF_ESTATE, "dealt tiles: more chunks than waves (rank %d)", r);
+                    used[(size_t)m * 4 + w] = 1;
+                    tab[slot(m, w)] = tile(r, tx, q);
+                }
+        }
+        if (c->tb_dealt_cap < entries) {
+            TRY(resident_check(c));
+            if (c->tb_dealt) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->tb_dealt)); c->tb_dealt = nullptr; }
+            HIP_TRY(hipMalloc((void **)&c->tb_dealt, entries * sizeof(int4)));
+            c->tb_dealt_cap = entries;
+        }
+        HIP_TRY(hipMemcpyAsync(c->tb_dealt, tab.data(), entries * sizeof(int4), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));                                   // (pageable source; once per plan change)
+        c->tb_dealt_key = key;
+        c->tb_dealt_LY = st[ntx / 2].ly[1];
+        c->tb_dealt_nmax = nmax;
+    }
+    fill_plan();
+    return DEFF_OK;
+}
+
 static int plan_streaming(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int own_h)
 {
     pl->impl = 1;
@@ -666,6 +807,12 @@ static int plan_streaming(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int own
     int resident = c->tb_wg;
     if (!resident) {
         TRY(tb_resident_blocks(c, T, pl->fma, c->lut_guard, &resident));
+    }
+    pl->dealt = nullptr;
+    if (c->tb_ranked && !c->tb_LY && !c->tb_wg && c->nimg == 1 && pl->band_h == 0 && !c->slab && T >= 6 && !c->masked) {
+        bool dealt = false;
+        TRY(deal_ranked_tiles(c, pl, T, own_lo, own_h, resident, &dealt));
+        if (dealt) return DEFF_OK;
     }
     int LY = c->tb_LY;
     if (!LY) {
@@ -704,6 +851,7 @@ static void record_plan(deff_ctx *c, const SweepPlan *pl)
     c->plan_R = pl->impl == 2 ? pl->R : 0;
     c->plan_NW = pl->impl == 2 ? pl->NW : 0;
     c->plan_resident = pl->impl == 2 && pl->resident ? 1 : 0;
+    c->plan_ranked = pl->impl == 1 && pl->dealt ? 1 : 0;
 }
 
 // The form of a blocked pass, in this order ("What the planner picks"): 8-wave tiles when they are all
@@ -908,7 +1056,7 @@ int launch_tb_pass(deff_ctx *c, const SweepPlan &pl)
                        c->code, xin, xout, c->nx, c->mesh_ny, c->ny, c->dom_lo, pl.own_lo, pl.own_h, pl.tcpi, \
                        mask, pl.LY, pl.ntx, pl.tgx, pl.tgy, flip, c->tb_xmajor,                              \
                        (c->lut_allb || c->nx != c->nxt) ? 1 : 0, /* padded: the wall column may not be in the last strip */ \
-                       c->lut_nrows, pl.shift, pl.omw, c->tb_stamps)
+                       c->lut_nrows, pl.shift, pl.omw, c->tb_stamps, pl.dealt)
     TB_DISPATCH(pl.T, pl.fma, pl.guard, LAUNCH_TB);
 #undef LAUNCH_TB
     HIP_TRY(hipPeekAtLastError());

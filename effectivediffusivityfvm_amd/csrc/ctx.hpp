@@ -185,6 +185,18 @@ struct deff_ctx {
     bool chain_counted = false;                  // this context is counted among its device's users of the resident chain's event
     int fma = 0;                                 // contracted arithmetic (kernels_sweep.hpp), opt-in
     int tb_xmajor = 1;                           // wave-tile numbering of the temporally blocked kernel
+    // Streaming kernel, chunk heights by service order (deal_ranked_tiles, api_solve.hip): 0 = equal chunks, 1 = dealt tiles.
+    // tb_rank_w: the relative speed (per mille) of a SIMD's oldest / second / youngest wave, tb_rank_wall: what a row of a wall strip
+    // costs, per mille of an inner strip's (its waves look up b as well)
+    int tb_ranked = 1;
+    int tb_rank_w[3] = {460, 325, 215};
+    int tb_rank_wall = 1100;
+    int4 *tb_dealt = nullptr;                    // device table: (strip, first row, rows, stamp index) per wave of the grid
+    size_t tb_dealt_cap = 0;
+    std::vector<int4> tb_dealt_host;
+    std::vector<int> tb_dealt_key;               // what the table was built for
+    int tb_dealt_LY = 0, tb_dealt_nmax = 0;      // ... and what deff_get_plan reports of it (an inner strip's middle rank; most chunks per rank)
+    int plan_ranked = 0;
     int64_t last_launches = 0;                   // sweep-kernel launches of the last deff_sweeps()/deff_solve()
 };
 
@@ -290,6 +302,7 @@ struct SweepPlan {
     bool guard = false;
     double omega = 0;                                     // as given to plan_sweeps (omw = 1 - omega)
     int impl = 1, R = 0, NW = 8;                          // 1 = streaming kernel, 2 = workgroup tiles of NW waves x R rows
+    const int4 *dealt = nullptr;                          // streaming kernel: dealt tiles (chunk heights by service order), or none
     bool resident = false;                                // impl 2 only: all passes of a batch in one launch (k_sweep_wgres)
     bool sym = false;                                     // tall tiles: the system is link-symmetric (7 lookups per row)
     // rows the plan updates: band_h > 0 restricts it to the band [band_lo, band_lo + band_h) of the context's owned rows

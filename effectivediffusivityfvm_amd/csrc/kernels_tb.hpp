@@ -304,7 +304,8 @@ __global__ __launch_bounds__(256, (T >= 6 ? 3 : 1)) void k_sweep_matfree_tb(cons
                                                           const uint8_t *__restrict__ active,
                                                           int LY, int ntx, int nbt, int gy, int flip,
                                                           int xmajor, int allb, int nrows, int shift,
-                                                          double omw, unsigned long long *__restrict__ stamps)
+                                                          double omw, unsigned long long *__restrict__ stamps,
+                                                          const int4 *__restrict__ dealt)
 {
     static_assert(T >= 1 && T <= 8, "unsupported T");
     __shared__ double lut[LUT_DOUBLES];
@@ -324,6 +325,24 @@ __global__ __launch_bounds__(256, (T >= 6 ? 3 : 1)) void k_sweep_matfree_tb(cons
     // diagnostics only (tools/tb_stamps.py): wall-clock start / end of every wave tile; the buffer is
     // written by lane 0 after the tile and read by nobody on the device
     const unsigned long long t_begin = stamps ? wall_clock64() : 0ull;
+    if (dealt) {
+        // Dealt tiles (one image, one tile per wave; plan_streaming / deal_ranked_tiles in api_solve.hip): wave `wave` of workgroup
+        // blockIdx.x runs the chunk the host wrote at dealt[4 * blockIdx.x + wave] = (strip, first row, rows, stamp index) --
+        // chunk heights then follow the order in which a SIMD serves its waves.  rows = 0: nothing for this wave.
+        const int4 d = dealt[(size_t)blockIdx.x * 4u + (unsigned)wave];
+        if (d.z <= 0) return;
+        if (allb || d.x == 0 || d.x == ntx - 1)
+            tb_strip<T, GUARD, true, FMA>(lut, code, x, xnew, nx, ny, dom_lo, own_lo + own_h, d.x, ntx, shift, d.y, d.z, lane, omw);
+        else
+            tb_strip<T, GUARD, false, FMA>(lut, code, x, xnew, nx, ny, dom_lo, own_lo + own_h, d.x, ntx, shift, d.y, d.z, lane, omw);
+        if (stamps && lane == 0) {
+            const unsigned long long where = (unsigned long long)(__builtin_amdgcn_s_getreg(0xF804) & 0xFFFFu) |
+                                             ((unsigned long long)(__builtin_amdgcn_s_getreg(0xF814) & 0xFu) << 16);
+            stamps[2 * (size_t)d.w] = t_begin;
+            stamps[2 * (size_t)d.w + 1] = ((wall_clock64() - t_begin) & 0xFFFFFFFFull) | (where << 32);
+        }
+        return;
+    }
     for (unsigned kk = blockIdx.x >> 3; kk < per; kk += nper) {
         const unsigned bt = xcd * per + (flip ? per - 1u - kk : kk);
         if (bt >= total) continue;
@@ -345,8 +364,11 @@ __global__ __launch_bounds__(256, (T >= 6 ? 3 : 1)) void k_sweep_matfree_tb(cons
         else
             tb_strip<T, GUARD, false, FMA>(lut, code, x, xnew, nx, ny, row_lo, own0 + own_h, tx, ntx, shift, ry0, LY, lane, omw);
         if (stamps && lane == 0) {
+            // end stamp: low 32 bits = duration in 10-ns ticks, bits 32...47 = HW_ID (wave slot, SIMD, CU, SE), 48...51 = XCC
+            const unsigned long long where = (unsigned long long)(__builtin_amdgcn_s_getreg(0xF804) & 0xFFFFu) |
+                                             ((unsigned long long)(__builtin_amdgcn_s_getreg(0xF814) & 0xFu) << 16);
             stamps[2 * (size_t)wt] = t_begin;
-            stamps[2 * (size_t)wt + 1] = wall_clock64();
+            stamps[2 * (size_t)wt + 1] = ((wall_clock64() - t_begin) & 0xFFFFFFFFull) | (where << 32);
         }
     }
 }

@@ -247,7 +247,8 @@ int deff_slab_rank_sweeps(deff_slab_rank *s, int64_t n, double omega, float *ms)
 int deff_slab_rank_solve(deff_slab_rank *s, double omega, double tol, int64_t max_iter,
                          int64_t check_every, deff_result *out, double *MFL, double *MFR);
 
-/* diagnostics: wall-clock (100 MHz) start/end of every wave tile of one temporally blocked pass */
+/* diagnostics: per wave tile of one temporally blocked pass of the streaming kernel two words -- the wall-clock (100 MHz) start,
+ * and duration (low 32 bits) | HW_ID[15:0] << 32 | XCC_ID << 48 (where it ran); resident tiles: 12 wall-clock stamps per tile */
 int deff_debug_tb_stamps(deff_ctx *ctx, double omega, unsigned long long *out, int *ntiles);
 
 /* raw device pointers for zero-copy interop (torch tensors, RCCL): current field, and the byte
