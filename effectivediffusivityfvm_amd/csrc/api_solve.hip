@@ -677,13 +677,16 @@ static int deal_ranked_tiles(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int 
     if (cus % xcds != 0 || occ != 3 || resident != occ * cus) return DEFF_OK;       // three waves per SIMD is what was measured
     const int slots = cus * 4;                                                       // waves per rank
     const int ntx = pl->ntx, cap = own_h / (3 * T);
-    const int nq = std::min(slots / ntx, cap);
+    const int ncol = ntx * c->nimg;                      // columns to cut into chunks: every strip of every image of a stack
+    if (ntx > 0xFFFF || c->nimg > 0x7FFF || ncol > slots) return DEFF_OK;
+    const int nq = std::min(slots / ncol, cap);
     if (nq < 1 || c->tb_rank_wall < 1000 || c->tb_rank_w[0] < 1 || c->tb_rank_w[1] < 1 || c->tb_rank_w[2] < 1) return DEFF_OK;
-    const std::vector<int> key = {T, own_lo, own_h, ntx, pl->shift, resident, c->tb_rank_w[0], c->tb_rank_w[1], c->tb_rank_w[2], c->tb_rank_wall};
+    const std::vector<int> key = {T, own_lo, own_h, ntx, c->nimg, pl->shift, resident, c->tb_rank_w[0], c->tb_rank_w[1], c->tb_rank_w[2], c->tb_rank_wall};
     auto fill_plan = [&]() {
         pl->dealt = c->tb_dealt;
         pl->LY = c->tb_dealt_LY;
-        pl->tcpi = pl->tgy = 3 * c->tb_dealt_nmax;                                   // (the stamps' numbering: rank, strip, chunk < nmax)
+        pl->tcpi = 3 * c->tb_dealt_nmax;                                             // (the stamps' numbering: rank, image, strip, chunk < nmax)
+        pl->tgy = pl->tcpi * c->nimg;
         pl->tgx = (ntx * pl->tgy + 3) / 4;
         pl->tblocks = resident;
         *dealt = true;
@@ -694,20 +697,22 @@ static int deal_ranked_tiles(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int 
     // A wall strip's waves look up b as well and run 10-15 % longer per row (mean end of a 4096^2 pass by strip, equal chunk
     // counts: 107 us in the first strip against 94...100 in the others): its rows count tb_rank_wall per mille.  A last strip
     // that is partly outside the mesh (4096 columns: half of it) moves fewer cache lines: the surcharge in proportion.
-    std::vector<double> weight(ntx, 1.0);
+    std::vector<double> weight(ncol, 1.0);
     const bool walls = ntx >= 3;
     if (walls) {
         const int hw = (T + 1) & ~1, wout = TB_COLS - 2 * hw;
         const int last_cols = c->nx - ((ntx - 1) * wout - pl->shift);                // columns of the last strip inside the mesh
-        weight[0] = c->tb_rank_wall / 1000.0;
-        weight[ntx - 1] = 1.0 + (c->tb_rank_wall / 1000.0 - 1.0) * std::min(last_cols, TB_COLS) / TB_COLS;
+        for (int img = 0; img < c->nimg; ++img) {
+            weight[(size_t)img * ntx] = c->tb_rank_wall / 1000.0;
+            weight[(size_t)img * ntx + ntx - 1] = 1.0 + (c->tb_rank_wall / 1000.0 - 1.0) * std::min(last_cols, TB_COLS) / TB_COLS;
+        }
     }
     // chunks per strip and rank: nq each, then the wave slots left over go one by one to the strip that would end last
     // (time of a strip = its level steps over the speed of its waves: w (T own_h + K sum n_r) / sum n_r v_r)
     struct Strip { int n[3]; int ly[3]; };
-    std::vector<Strip> st(ntx);
+    std::vector<Strip> st(ncol);
     for (auto &q : st) q.n[0] = q.n[1] = q.n[2] = nq;
-    int spare[3] = {slots - ntx * nq, slots - ntx * nq, slots - ntx * nq};
+    int spare[3] = {slots - ncol * nq, slots - ncol * nq, slots - ncol * nq};
     auto strip_time = [&](int tx) {
         const Strip &q = st[tx];
         return weight[tx] * ((double)T * own_h + (double)K * (q.n[0] + q.n[1] + q.n[2])) / (q.n[0] * v[0] + q.n[1] * v[1] + q.n[2] * v[2]);
@@ -715,7 +720,7 @@ static int deal_ranked_tiles(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int 
     for (int it = 0; it < 3 * slots; ++it) {
         int worst = -1;
         double tw = 0;
-        for (int tx = 0; tx < ntx; ++tx) {
+        for (int tx = 0; tx < ncol; ++tx) {
             const double t = strip_time(tx);
             if (t > tw) { tw = t; worst = tx; }
         }
@@ -728,7 +733,7 @@ static int deal_ranked_tiles(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int 
     }
     // chunk heights: a rank's chunk gets the rows its waves finish in the strip's time; the oldest rank takes the rounding
     int nmax = 0;
-    for (int tx = 0; tx < ntx; ++tx) {
+    for (int tx = 0; tx < ncol; ++tx) {
         Strip &q = st[tx];
         const double t = strip_time(tx) / weight[tx];
         int left = own_h;
@@ -746,15 +751,17 @@ static int deal_ranked_tiles(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int 
     {
         std::vector<int4> &tab = c->tb_dealt_host;
         tab.assign(entries, make_int4(0, 0, 0, 0));
-        const int own_hi = own_lo + own_h;
-        auto tile = [&](int r, int tx, int q) {
-            const Strip &sp = st[tx];
-            int ry0 = own_lo;
+        auto tile = [&](int r, int col, int q) {
+            const Strip &sp = st[col];
+            const int img = col / ntx, tx = col % ntx;
+            const int own0 = own_lo + img * c->ny;                                  // (c->ny: the row pitch of a stack's images)
+            const int own_hi = own0 + own_h;
+            int ry0 = own0;
             for (int k = 0; k < r; ++k) ry0 += sp.n[k] * sp.ly[k];
             ry0 += q * sp.ly[r];
             int rows_here = std::min(sp.ly[r], own_hi - ry0);
             if (r == 2 && q == sp.n[2] - 1) rows_here = own_hi - ry0;              // the youngest rank's last chunk takes what rounding left over
-            return make_int4(tx, ry0, rows_here > 0 ? rows_here : 0, (r * ntx + tx) * nmax + q);
+            return make_int4(tx | (img << 16), ry0, rows_here > 0 ? rows_here : 0, ((r * c->nimg + img) * ntx + tx) * nmax + q);
         };
         for (int r = 0; r < 3; ++r) {
             // workgroup m of rank r: XCD m / per_xcd, the (m % per_xcd)-th of that XCD's workgroups of this rank
@@ -764,8 +771,9 @@ static int deal_ranked_tiles(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int 
             // were the last to end by 5 us), each rank starting elsewhere
             std::vector<int4> wall_tiles;
             if (walls)
-                for (int tx : {0, ntx - 1})
-                    for (int q = 0; q < st[tx].n[r]; ++q) wall_tiles.push_back(tile(r, tx, q));
+                for (int img = 0; img < c->nimg; ++img)
+                    for (int tx : {0, ntx - 1})
+                        for (int q = 0; q < st[(size_t)img * ntx + tx].n[r]; ++q) wall_tiles.push_back(tile(r, img * ntx + tx, q));
             const int nw = (int)wall_tiles.size();
             for (int k = 0; k < nw; ++k) {
                 int m = (int)(((long)k * cus) / std::max(nw, 1) + (long)r * cus / 3) % cus, w = 0;
@@ -775,13 +783,15 @@ static int deal_ranked_tiles(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int 
             }
             // the inner strips in order (chunk index fastest): a workgroup's waves hold stacked chunks, an XCD neighbouring strips
             int m = 0, w = 0;
-            for (int tx = walls ? 1 : 0; tx < (walls ? ntx - 1 : ntx); ++tx)
-                for (int q = 0; q < st[tx].n[r]; ++q) {
+            for (int col = 0; col < ncol; ++col) {
+                if (walls && (col % ntx == 0 || col % ntx == ntx - 1)) continue;
+                for (int q = 0; q < st[col].n[r]; ++q) {
                     while (m < cus && used[(size_t)m * 4 + w]) { if (++w == 4) { w = 0; ++m; } }
                     if (m >= cus) return fail(DEFF_ESTATE, "dealt tiles: more chunks than waves (rank %d)", r);
                     used[(size_t)m * 4 + w] = 1;
-                    tab[slot(m, w)] = tile(r, tx, q);
+                    tab[slot(m, w)] = tile(r, col, q);
                 }
+            }
         }
         if (c->tb_dealt_cap < entries) {
             TRY(resident_check(c));
@@ -809,7 +819,7 @@ static int plan_streaming(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int own
         TRY(tb_resident_blocks(c, T, pl->fma, c->lut_guard, &resident));
     }
     pl->dealt = nullptr;
-    if (c->tb_ranked && !c->tb_LY && !c->tb_wg && c->nimg == 1 && pl->band_h == 0 && !c->slab && T >= 6 && !c->masked) {
+    if (c->tb_ranked && !c->tb_LY && !c->tb_wg && pl->band_h == 0 && !c->slab && T >= 6 && !c->masked) {
         bool dealt = false;
         TRY(deal_ranked_tiles(c, pl, T, own_lo, own_h, resident, &dealt));
         if (dealt) return DEFF_OK;

@@ -326,15 +326,18 @@ __global__ __launch_bounds__(256, (T >= 6 ? 3 : 1)) void k_sweep_matfree_tb(cons
     // written by lane 0 after the tile and read by nobody on the device
     const unsigned long long t_begin = stamps ? wall_clock64() : 0ull;
     if (dealt) {
-        // Dealt tiles (one image, one tile per wave; plan_streaming / deal_ranked_tiles in api_solve.hip): wave `wave` of workgroup
-        // blockIdx.x runs the chunk the host wrote at dealt[4 * blockIdx.x + wave] = (strip, first row, rows, stamp index) --
+        // Dealt tiles (one tile per wave; plan_streaming / deal_ranked_tiles in api_solve.hip): wave `wave` of workgroup
+        // blockIdx.x runs the chunk the host wrote at dealt[4 * blockIdx.x + wave] = (strip | image << 16, first row, rows, stamp index) --
         // chunk heights then follow the order in which a SIMD serves its waves.  rows = 0: nothing for this wave.
         const int4 d = dealt[(size_t)blockIdx.x * 4u + (unsigned)wave];
         if (d.z <= 0) return;
-        if (allb || d.x == 0 || d.x == ntx - 1)
-            tb_strip<T, GUARD, true, FMA>(lut, code, x, xnew, nx, ny, dom_lo, own_lo + own_h, d.x, ntx, shift, d.y, d.z, lane, omw);
+        const int tx = d.x & 0xFFFF, img = d.x >> 16;      // image of a stack
+        if (active && !active[img]) return;
+        const int row_lo = dom_lo + img * img_stride, own_hi = own_lo + img * img_stride + own_h;
+        if (allb || tx == 0 || tx == ntx - 1)
+            tb_strip<T, GUARD, true, FMA>(lut, code, x, xnew, nx, ny, row_lo, own_hi, tx, ntx, shift, d.y, d.z, lane, omw);
         else
-            tb_strip<T, GUARD, false, FMA>(lut, code, x, xnew, nx, ny, dom_lo, own_lo + own_h, d.x, ntx, shift, d.y, d.z, lane, omw);
+            tb_strip<T, GUARD, false, FMA>(lut, code, x, xnew, nx, ny, row_lo, own_hi, tx, ntx, shift, d.y, d.z, lane, omw);
         if (stamps && lane == 0) {
             const unsigned long long where = (unsigned long long)(__builtin_amdgcn_s_getreg(0xF804) & 0xFFFFu) |
                                              ((unsigned long long)(__builtin_amdgcn_s_getreg(0xF814) & 0xFu) << 16);

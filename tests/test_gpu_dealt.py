@@ -56,7 +56,7 @@ def test_dealt_tiles_vs_oracle_and_equal_chunks(pkg, oracle, shape, T):
         assert np.array_equal(skew, want), tune
 
 
-def test_dealt_tiles_are_the_default_at_4096_and_leave_stacks_alone(pkg):
+def test_dealt_tiles_are_the_default_at_4096_and_for_stacks(pkg):
     with pkg.Solver(4096, 4096) as s:
         s.synth_image(12345, 0)
         s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
@@ -71,7 +71,35 @@ def test_dealt_tiles_are_the_default_at_4096_and_leave_stacks_alone(pkg):
         s.init_linear(0.0, 1.0)
         s.sweeps(16)
         p = s.plan()
-        assert p["tb_impl"] == 1 and p["tb_ranked"] == 0, p
+        assert p["tb_impl"] == 1 and p["tb_ranked"] == 1, p
+
+
+def test_dealt_tiles_on_a_stack_whose_images_stop_at_different_checks(pkg, oracle):
+    """Every (image, strip) column of a stack is cut into its own chunks; images that have met the tolerance leave the launch
+    (their tiles return at once) and keep their field."""
+    nx, ny, B = 300, 260, 5
+    rng = np.random.default_rng(21)
+    pixs = [rand_mask(rng, nx, ny, 0.35 + 0.1 * k) for k in range(B)]
+    for ranked in (1, 0):
+        with pkg.Solver(nx, ny, nimg=B, kernel="matfree_tb") as s:
+            s.set_tuning("tb_impl", 1); s.set_tuning("tb_T", 8); s.set_tuning("tb_ranked", ranked)
+            s.set_image(np.stack(pixs))
+            s.assemble_2phase(1e-2, 1.0, 0.0, 1.0)
+            s.init_linear(0.0, 1.0)
+            s.sweeps(24)
+            assert s.plan()["tb_ranked"] == ranked and s.plan()["tb_impl"] == 1
+            s.init_linear(0.0, 1.0)
+            res = s.solve(1e-3, 6000, check_every=200)
+            got = s.get_field()
+        iters = set()
+        for k in range(B):
+            D = oracle.fill_D_2phase(pixs[k], 1.0, 1e-2)
+            A, b = oracle.discretize(D, 0.0, 1.0)
+            it, deff, conv, x, _, _ = oracle.jacobi(A, b, oracle.linear_guess(nx, ny, 0.0, 1.0), D, 0.0, 1.0, 1e-3, 6000, check_every=200)
+            assert (res[k].iters, res[k].deff_raw, res[k].conv) == (it, deff, conv)
+            assert np.array_equal(got[k * ny:(k + 1) * ny], x)
+            iters.add(it)
+        assert len(iters) > 1
 
 
 def test_dealt_tiles_on_a_dictionary_system_and_omega_one(pkg, oracle):
