@@ -819,7 +819,8 @@ static int plan_streaming(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int own
         TRY(tb_resident_blocks(c, T, pl->fma, c->lut_guard, &resident));
     }
     pl->dealt = nullptr;
-    if (c->tb_ranked && !c->tb_LY && !c->tb_wg && pl->band_h == 0 && !c->slab && T >= 6 && !c->masked) {
+    // (T = 8 only: the ranks' speeds were measured there; with them T = 6 gains 3 % at 4096^2 and loses 4 % at 8192^2)
+    if (c->tb_ranked && !c->tb_LY && !c->tb_wg && pl->band_h == 0 && !c->slab && T == 8 && !c->masked) {
         bool dealt = false;
         TRY(deal_ranked_tiles(c, pl, T, own_lo, own_h, resident, &dealt));
         if (dealt) return DEFF_OK;

@@ -212,11 +212,11 @@ __device__ __forceinline__ void tb_strip(const double *lut, const uint16_t *__re
 #pragma unroll
     for (int k = 0; k < 3; ++k) fetch(r_begin + k, nx_x[k], nx_c[k]);
 
-    // (Measured with the tile time stamps, tools/tb_stamps.py: waves sharing a SIMD are served
-    // oldest-first, so identical tiles finish between 82 and 128 us inside one T = 8 launch.  A
-    // self-balancing s_setprio -- each wave lowering its priority as it advances -- narrowed that to
-    // 88..119 us but left the back-to-back launch rate unchanged (the SIMDs are throughput-bound;
-    // the early finishers' share goes to the rest), so it is not kept.)
+    // (Measured with the tile time stamps, tools/tb_stamps.py: waves sharing a SIMD are served oldest-first, so identical
+    // tiles end at 71 / 89 / 108 us of one T = 8 launch at 4096^2, by wave slot.  Evening that out with s_setprio -- a
+    // rotating priority per group of steps -- brought +2...4 %: served in turn the three waves issue less in total than served
+    // oldest-first.  What is kept is the other way round: the service order stays and the TILES differ, the oldest wave of a
+    // SIMD getting the tallest chunk -- `dealt` below, deal_ranked_tiles in api_solve.hip: +6...8 %.)
     // One group of three steps (input rows r, r+1, r+2).  TRIM = the group may contain levels whose
     // output row this chunk does not need: sweep t needs rows from max(mesh top, ry0 - (T - t)) on, and
     // produces row rr - t at the step that reads row rr, so for the first 2T steps of a chunk (T at the

@@ -68,7 +68,7 @@ with pkg.Solver(n, n) as s:
     for sl in np.unique(slot):
         v = kk[slot == sl]
         print(f"  wave slot {sl}: workgroups kk (position in its XCD's dispatch order) min {v.min()} p5 {int(np.percentile(v, 5))} median {int(np.median(v))} p95 {int(np.percentile(v, 95))} max {v.max()}")
-    # the stragglers: which tiles end last?  (streaming kernel's strip-major numbering: wt = tx * gy + chunk)
+    # the stragglers: which tiles end last?
     plan = s.plan()
     gy = plan["tb_chunks_per_image"]
     late = np.argsort(en)[::-1][:24]
@@ -87,8 +87,9 @@ with pkg.Solver(n, n) as s:
         txd = (wt_all % per_cls) // nq
         print("  mean end by strip: " + " ".join(f"{t}:{en[txd == t].mean():.0f}" for t in np.unique(txd)))
         sys.exit(0)
-    print("  last 24 tiles to end: " + "  ".join(f"[tx {wt_all[i] // gy} ch {wt_all[i] % gy} xcc {where[i] >> 16} cu {(where[i] >> 8) & 15} se {(where[i] >> 13) & 7} simd {(where[i] >> 4) & 3} slot {where[i] & 15}: {en[i]:.1f}]" for i in late))
-    txs = wt_all // gy
+    ntx_ = plan["tb_strips"]                                        # equal chunks, default numbering (tb_xmajor = 1): wt = chunk * strips + strip
+    print("  last 24 tiles to end: " + "  ".join(f"[tx {wt_all[i] % ntx_} ch {wt_all[i] // ntx_} xcc {where[i] >> 16} cu {(where[i] >> 8) & 15} se {(where[i] >> 13) & 7} simd {(where[i] >> 4) & 3} slot {where[i] & 15}: {en[i]:.1f}]" for i in late))
+    txs = wt_all % ntx_
     for name, m in (("first strip", txs == 0), ("last strip", txs == txs.max()), ("inner strips", (txs > 0) & (txs < txs.max()))):
         for sl in (0, 1, 2):
             mm = m & (slot == sl)
