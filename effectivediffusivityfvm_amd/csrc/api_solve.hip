@@ -6,6 +6,7 @@
 #include "kernels_sweep.hpp"
 #include "kernels_tb.hpp"
 #include "kernels_wgtile.hpp"
+#include <array>
 #include <mutex>
 
 // ----------------------------------------------------------- sweeps -------
@@ -697,25 +698,31 @@ static int deal_ranked_tiles(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int 
     // A wall strip's waves look up b as well and run 10-15 % longer per row (mean end of a 4096^2 pass by strip, equal chunk
     // counts: 107 us in the first strip against 94...100 in the others): its rows count tb_rank_wall per mille.  A last strip
     // that is partly outside the mesh (4096 columns: half of it) moves fewer cache lines: the surcharge in proportion.
-    std::vector<double> weight(ncol, 1.0);
+    // (the surcharge differs by rank: the oldest wave runs at the pace of its own dependency chain and pays every extra lookup --
+    // its wall chunks ended 12-14 % after the rank's mean --, the youngest waits for issue slots anyway: 6 %)
+    std::vector<std::array<double, 3>> speed(ncol, std::array<double, 3>{v[0], v[1], v[2]});
     const bool walls = ntx >= 3;
     if (walls) {
         const int hw = (T + 1) & ~1, wout = TB_COLS - 2 * hw;
         const int last_cols = c->nx - ((ntx - 1) * wout - pl->shift);                // columns of the last strip inside the mesh
-        for (int img = 0; img < c->nimg; ++img) {
-            weight[(size_t)img * ntx] = c->tb_rank_wall / 1000.0;
-            weight[(size_t)img * ntx + ntx - 1] = 1.0 + (c->tb_rank_wall / 1000.0 - 1.0) * std::min(last_cols, TB_COLS) / TB_COLS;
-        }
+        const double extra = c->tb_rank_wall / 1000.0 - 1.0, by_rank[3] = {2.5, 1.5, 1.0};
+        const double fill = (double)std::min(last_cols, TB_COLS) / TB_COLS;
+        for (int img = 0; img < c->nimg; ++img)
+            for (int r = 0; r < 3; ++r) {
+                speed[(size_t)img * ntx][r] = v[r] / (1.0 + extra * by_rank[r]);
+                speed[(size_t)img * ntx + ntx - 1][r] = v[r] / (1.0 + extra * by_rank[r] * fill);
+            }
     }
     // chunks per strip and rank: nq each, then the wave slots left over go one by one to the strip that would end last
-    // (time of a strip = its level steps over the speed of its waves: w (T own_h + K sum n_r) / sum n_r v_r)
+    // (time of a strip = its level steps over the speed of its waves: (T own_h + K sum n_r) / sum n_r v_r)
     struct Strip { int n[3]; int ly[3]; };
     std::vector<Strip> st(ncol);
     for (auto &q : st) q.n[0] = q.n[1] = q.n[2] = nq;
     int spare[3] = {slots - ncol * nq, slots - ncol * nq, slots - ncol * nq};
     auto strip_time = [&](int tx) {
         const Strip &q = st[tx];
-        return weight[tx] * ((double)T * own_h + (double)K * (q.n[0] + q.n[1] + q.n[2])) / (q.n[0] * v[0] + q.n[1] * v[1] + q.n[2] * v[2]);
+        const std::array<double, 3> &u = speed[tx];
+        return ((double)T * own_h + (double)K * (q.n[0] + q.n[1] + q.n[2])) / (q.n[0] * u[0] + q.n[1] * u[1] + q.n[2] * u[2]);
     };
     for (int it = 0; it < 3 * slots; ++it) {
         int worst = -1;
@@ -735,10 +742,10 @@ static int deal_ranked_tiles(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int 
     int nmax = 0;
     for (int tx = 0; tx < ncol; ++tx) {
         Strip &q = st[tx];
-        const double t = strip_time(tx) / weight[tx];
+        const double t = strip_time(tx);
         int left = own_h;
         for (int r = 2; r >= 1; --r) {
-            int ly = (int)((t * v[r] - K) / T);
+            int ly = (int)((t * speed[tx][r] - K) / T);
             if (ly < T) ly = T;
             q.ly[r] = ly;
             left -= q.n[r] * ly;
