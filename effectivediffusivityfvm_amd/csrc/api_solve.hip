@@ -754,7 +754,8 @@ static int deal_ranked_tiles(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int 
         if (q.ly[0] < T) return DEFF_OK;
         nmax = std::max(nmax, std::max(q.n[0], std::max(q.n[1], q.n[2])));
     }
-    const size_t entries = (size_t)resident * 4;
+    if ((long)3 * c->nimg * ntx * nmax >= (1L << 30)) return DEFF_OK;
+    const size_t entries = (size_t)resident * 4 + 1;              // + the word the waves count their misplacements in (kernels_tb.hpp)
     {
         std::vector<int4> &tab = c->tb_dealt_host;
         tab.assign(entries, make_int4(0, 0, 0, 0));
@@ -768,7 +769,7 @@ static int deal_ranked_tiles(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int 
             ry0 += q * sp.ly[r];
             int rows_here = std::min(sp.ly[r], own_hi - ry0);
             if (r == 2 && q == sp.n[2] - 1) rows_here = own_hi - ry0;              // the youngest rank's last chunk takes what rounding left over
-            return make_int4(tx | (img << 16), ry0, rows_here > 0 ? rows_here : 0, ((r * c->nimg + img) * ntx + tx) * nmax + q);
+            return make_int4(tx | (img << 16), ry0, rows_here > 0 ? rows_here : 0, (int)((unsigned)(((r * c->nimg + img) * ntx + tx) * nmax + q) | ((unsigned)r << 30)));
         };
         for (int r = 0; r < 3; ++r) {
             // workgroup m of rank r: XCD m / per_xcd, the (m % per_xcd)-th of that XCD's workgroups of this rank
@@ -811,6 +812,9 @@ static int deal_ranked_tiles(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int 
         c->tb_dealt_key = key;
         c->tb_dealt_LY = st[ntx / 2].ly[1];
         c->tb_dealt_nmax = nmax;
+        c->tb_dealt_miss_at = (size_t)resident * 4;
+        c->tb_dealt_waves = 0;
+        c->tb_dealt_looks = 0;
     }
     fill_plan();
     return DEFF_OK;
@@ -827,7 +831,7 @@ static int plan_streaming(deff_ctx *c, SweepPlan *pl, int T, int own_lo, int own
     }
     pl->dealt = nullptr;
     // (T = 8 only: the ranks' speeds were measured there; with them T = 6 gains 3 % at 4096^2 and loses 4 % at 8192^2)
-    if (c->tb_ranked && !c->tb_LY && !c->tb_wg && pl->band_h == 0 && !c->slab && T == 8 && !c->masked) {
+    if (c->tb_ranked && !c->tb_rank_lost && !c->tb_LY && !c->tb_wg && pl->band_h == 0 && !c->slab && T == 8 && !c->masked) {
         bool dealt = false;
         TRY(deal_ranked_tiles(c, pl, T, own_lo, own_h, resident, &dealt));
         if (dealt) return DEFF_OK;
@@ -1041,6 +1045,22 @@ void enqueue_sweep(deff_ctx *c, const SweepPlan &pl)
     c->cur ^= 1;
 }
 
+// Is the chip dispatching the way the dealt tiles assume?  Called where the stream has just been synchronised, for the first
+// three such points after a table was built: the waves that found themselves in another slot than their tile was cut for have
+// counted themselves (kernels_tb.hpp).  More than a quarter of them misplaced -- somebody else's kernels on the GPU, another
+// dispatch order -- and the context goes back to equal chunks; the results are the same bits either way.
+int dealt_watch(deff_ctx *c)
+{
+    if (!c->tb_dealt || c->tb_dealt_looks >= 3 || c->tb_dealt_waves == 0) return DEFF_OK;
+    unsigned miss = 0;
+    HIP_TRY(hipMemcpyAsync(&miss, reinterpret_cast<const char *>(c->tb_dealt + c->tb_dealt_miss_at), sizeof miss, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ++c->tb_dealt_looks;
+    c->tb_rank_misses = (int)std::min<int64_t>(miss, INT32_MAX);
+    if ((int64_t)miss * 4 > c->tb_dealt_waves) c->tb_rank_lost = 1;
+    return DEFF_OK;
+}
+
 // One temporally blocked pass: T sweeps, x[cur] -> x[cur^1].
 int enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl)
 {
@@ -1078,6 +1098,7 @@ int launch_tb_pass(deff_ctx *c, const SweepPlan &pl)
     TB_DISPATCH(pl.T, pl.fma, pl.guard, LAUNCH_TB);
 #undef LAUNCH_TB
     HIP_TRY(hipPeekAtLastError());
+    if (pl.dealt) c->tb_dealt_waves += (int64_t)pl.tblocks * 4;
     return DEFF_OK;
 }
 
@@ -1172,6 +1193,7 @@ try {
     HIP_TRY(hipEventSynchronize(c->ev1));
     if (ms) HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
     TRY(resident_check(c));
+    TRY(dealt_watch(c));
     return DEFF_OK;
 }
 DEFF_API_CATCH
@@ -1199,12 +1221,12 @@ int flux_rows(deff_ctx *c, bool need_rows)
         c->q_valid = true;
         if (!need_rows) {
             HIP_TRY(hipStreamSynchronize(c->stream));
-            return DEFF_OK;
+            return dealt_watch(c);
         }
     }
     HIP_TRY(hipMemcpyAsync(c->mf_host, c->mf, sizeof(double) * 2 * c->rows, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return DEFF_OK;
+    return dealt_watch(c);
 }
 
 // Deff of image k from its wall fluxes, summed in row order like the reference (cuh:1258-1263): on the host from

@@ -195,6 +195,10 @@ struct deff_ctx {
     size_t tb_dealt_cap = 0;
     std::vector<int4> tb_dealt_host;
     std::vector<int> tb_dealt_key;               // what the table was built for
+    size_t tb_dealt_miss_at = 0;                 // index of the table's last element: the waves' count of misplacements
+    int64_t tb_dealt_waves = 0;                  // waves launched on the current table
+    int tb_dealt_looks = 0;                      // times the count was read (dealt_watch: the first three synchronisations)
+    int tb_rank_misses = 0, tb_rank_lost = 0;    // last count read; 1 = the dispatch order is not the assumed one: equal chunks from now on
     int tb_dealt_LY = 0, tb_dealt_nmax = 0;      // ... and what deff_get_plan reports of it (an inner strip's middle rank; most chunks per rank)
     int plan_ranked = 0;
     int64_t last_launches = 0;                   // sweep-kernel launches of the last deff_sweeps()/deff_solve()
@@ -326,6 +330,7 @@ int plan_sweeps(deff_ctx *c, double omega, SweepPlan *pl);
 void enqueue_sweep(deff_ctx *c, const SweepPlan &pl);
 int enqueue_tb_pass(deff_ctx *c, const SweepPlan &pl);
 int launch_tb_pass(deff_ctx *c, const SweepPlan &pl);    // the same launch without flipping x[cur]
+int dealt_watch(deff_ctx *c);                            // after a synchronisation: is the dispatch order the dealt tiles assume?
 int enqueue_sweeps(deff_ctx *c, const SweepPlan &pl, int64_t n);   // stops at the first launch that fails
 // did a resident launch give up waiting?  (synchronises if one is pending; on an abort the interval is redone with one
 // launch per pass and the context stays in that mode)

@@ -331,6 +331,12 @@ __global__ __launch_bounds__(256, (T >= 6 ? 3 : 1)) void k_sweep_matfree_tb(cons
         // chunk heights then follow the order in which a SIMD serves its waves.  rows = 0: nothing for this wave.
         const int4 d = dealt[(size_t)blockIdx.x * 4u + (unsigned)wave];
         if (d.z <= 0) return;
+        // the deal rests on an observation -- workgroup (blockIdx >> 3) / (CUs per XCD) of an XCD lands in wave slot 0, 1, 2 of its
+        // SIMDs -- and watches it: a wave that finds itself in another slot than its tile was cut for counts itself in the word
+        // behind the table; the host reads the count after the first launches of a plan and goes back to equal chunks if the
+        // chip is not dispatching that way (another process on the GPU).  d.w = stamp index | slot << 30.
+        if (lane == 0 && __builtin_amdgcn_s_getreg(0x1804) != ((unsigned)d.w >> 30))
+            atomicAdd(reinterpret_cast<unsigned *>(const_cast<int4 *>(dealt) + (size_t)gridDim.x * 4u), 1u);
         const int tx = d.x & 0xFFFF, img = d.x >> 16;      // image of a stack
         if (active && !active[img]) return;
         const int row_lo = dom_lo + img * img_stride, own_hi = own_lo + img * img_stride + own_h;
@@ -341,8 +347,9 @@ __global__ __launch_bounds__(256, (T >= 6 ? 3 : 1)) void k_sweep_matfree_tb(cons
         if (stamps && lane == 0) {
             const unsigned long long where = (unsigned long long)(__builtin_amdgcn_s_getreg(0xF804) & 0xFFFFu) |
                                              ((unsigned long long)(__builtin_amdgcn_s_getreg(0xF814) & 0xFu) << 16);
-            stamps[2 * (size_t)d.w] = t_begin;
-            stamps[2 * (size_t)d.w + 1] = ((wall_clock64() - t_begin) & 0xFFFFFFFFull) | (where << 32);
+            const size_t si = (size_t)(d.w & 0x3FFFFFFF);
+            stamps[2 * si] = t_begin;
+            stamps[2 * si + 1] = ((wall_clock64() - t_begin) & 0xFFFFFFFFull) | (where << 32);
         }
         return;
     }

@@ -145,3 +145,46 @@ def test_dealt_tiles_on_three_permeable_classes(pkg, oracle):
         s.sweeps(35)
         assert s.kernel_in_use() == "matfree_tb" and s.plan()["tb_ranked"] == 1, s.plan()
         assert np.array_equal(s.get_field(), want)
+
+
+def test_the_deal_watches_its_assumption(pkg):
+    """On a GPU this process has to itself the waves land in the slots their tiles were cut for (no misses, dealing stays on);
+    with a second context sweeping on another stream at the same time they do not, the count says so, and whichever way the
+    watch decides the fields are the same bits."""
+    import threading
+    n = 4096
+    with pkg.Solver(n, n) as s:
+        s.synth_image(12345, 0)
+        s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+        s.init_linear(0.0, 1.0)
+        for _ in range(4):
+            s.sweeps(64)
+        assert s.plan()["tb_ranked"] == 1
+        assert s.plan_value("tb_rank_lost") == 0 and s.plan_value("tb_rank_misses") <= 3072 * 8 // 50, s.plan_value("tb_rank_misses")
+        alone = s.get_field()
+    stop = threading.Event()
+
+    def disturb():
+        with pkg.Solver(2048, 2048, kernel="explicit") as d:
+            d.synth_image(7, 0)
+            d.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            d.init_linear(0.0, 1.0)
+            while not stop.is_set():
+                d.sweeps(50)
+
+    th = threading.Thread(target=disturb)
+    th.start()
+    try:
+        with pkg.Solver(n, n) as s:
+            s.synth_image(12345, 0)
+            s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            s.init_linear(0.0, 1.0)
+            for _ in range(4):
+                s.sweeps(64)
+            print("with a second context sweeping: misses", s.plan_value("tb_rank_misses"), "lost", s.plan_value("tb_rank_lost"),
+                  "dealt in the last plan", s.plan()["tb_ranked"])
+            shared = s.get_field()
+    finally:
+        stop.set()
+        th.join()
+    assert np.array_equal(alone, shared)
