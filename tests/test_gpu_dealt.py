@@ -188,3 +188,36 @@ def test_the_deal_watches_its_assumption(pkg):
         stop.set()
         th.join()
     assert np.array_equal(alone, shared)
+
+
+def test_dealt_tiles_fuzz_against_equal_chunks(pkg):
+    """40 random contexts -- shape, stack size, weights, wall surcharge -- swept with dealt tiles and with equal chunks: every
+    table must cover every row of every image exactly once, i.e. give the same field bit for bit."""
+    rng = np.random.default_rng(2026)
+    dealt = 0
+    for case in range(40):
+        nx = int(rng.integers(2, 1400))
+        ny = int(rng.integers(24, 700))
+        B = int(rng.choice([1, 1, 2, 3, 5]))
+        if nx * ny * B > 1_500_000:
+            B = 1
+        pix = np.where(rng.random((B * ny, nx)) < 0.5, 0, 255).astype(np.uint8)
+        x0 = rng.random((B * ny, nx))
+        w = sorted((int(v) for v in rng.integers(50, 900, size=3)), reverse=True)
+        tune = {"tb_rank_w0": w[0], "tb_rank_w1": w[1], "tb_rank_w2": w[2], "tb_rank_wall": int(rng.integers(1000, 2000))}
+        k = int(rng.integers(8, 30))
+        out = []
+        for ranked in (1, 0):
+            with pkg.Solver(nx, ny, nimg=B, kernel="matfree_tb") as s:
+                s.set_tuning("tb_impl", 1); s.set_tuning("tb_T", 8); s.set_tuning("tb_ranked", ranked)
+                for key, v in tune.items():
+                    s.set_tuning(key, v)
+                s.set_image(pix)
+                s.assemble_2phase(1e-3, 1.0, 0.25, 0.75)
+                s.set_field(x0)
+                s.sweeps(k)
+                out.append(s.get_field())
+                if ranked:
+                    dealt += s.plan()["tb_ranked"]
+        assert np.array_equal(out[0], out[1]), (case, nx, ny, B, tune, k)
+    assert dealt >= 30
