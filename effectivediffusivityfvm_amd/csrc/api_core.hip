@@ -271,6 +271,7 @@ try {
     else if (!strcmp(key, "tb_wall_halo")) c->tb_wall_halo = value > 2 ? 2 : value;
     else if (!strcmp(key, "tb_wg")) c->tb_wg = (value + 7) / 8 * 8;
     else if (!strcmp(key, "tb_ranked")) { c->tb_ranked = value ? 1 : 0; c->tb_rank_lost = 0; }
+    else if (!strcmp(key, "tb_tall_deal")) c->tb_tall_deal = value ? 1 : 0;
     else if (!strcmp(key, "tb_rank_w0")) c->tb_rank_w[0] = value;
     else if (!strcmp(key, "tb_rank_w1")) c->tb_rank_w[1] = value;
     else if (!strcmp(key, "tb_rank_w2")) c->tb_rank_w[2] = value;
@@ -296,6 +297,7 @@ try {
     else if (!strcmp(key, "tb_NW")) *value = c->plan_NW;
     else if (!strcmp(key, "tb_fallbacks")) *value = c->res_fallbacks;
     else if (!strcmp(key, "tb_ranked")) *value = c->plan_ranked;
+    else if (!strcmp(key, "tb_aged")) *value = c->plan_aged;
     else if (!strcmp(key, "tb_rank_misses")) *value = c->tb_rank_misses;
     else if (!strcmp(key, "tb_rank_lost")) *value = c->tb_rank_lost;
     else return fail(DEFF_EINVAL, "unknown plan key '%s'", key);

@@ -289,6 +289,26 @@ static hipError_t launch_wgres(deff_ctx *c, const SweepPlan &pl, double *xa, dou
     return launch_resident(c, pl, k_sweep_wgres<T, R, F, G, TALL, SYM>, (TALL ? WGL_WAVES : WGT_WAVES) * 64, xa, xb, npass, base);
 }
 
+template <int RA, int RB, int RC, int RD, bool F, bool G, bool SYM>
+static hipError_t launch_wgage(deff_ctx *c, const SweepPlan &pl, double *xa, double *xb, int npass, unsigned base)
+{
+    return launch_resident(c, pl, k_sweep_wgage<8, RA, RB, RC, RD, F, G, SYM>, WGL_WAVES * 64, xa, xb, npass, base);
+}
+
+// Rows by age for the tall tiles of R rows per wave (k_sweep_wgage): the 4R rows of a SIMD's four waves, oldest first.  Measured,
+// not derived (profiles/r04_tall_rows_by_age_kbench.log: four candidate sets per R, one process, against equal rows): what wins
+// gives the youngest wave about half its share and keeps the three older ones level; bodies of 9 and more rows spill, which is why
+// R = 7 stops at 8 rows and R = 9 and 13 found no set that beats equal rows (14 x 4 has nothing to deal).  Link-symmetric,
+// unguarded systems only (the 2-phase assembly and what tb_sym verifies), both arithmetics.
+#define WGAGE_SETS(X) X(5, 6, 6, 5, 3) X(6, 8, 8, 5, 3) X(7, 8, 8, 8, 4) X(8, 9, 9, 9, 5) X(10, 12, 12, 10, 6) X(11, 13, 13, 11, 7) X(12, 13, 13, 13, 9)
+static bool wgage_has(int R)
+{
+#define X(R_, A_, B_, C_, D_) if (R == R_) return true;
+    WGAGE_SETS(X)
+#undef X
+    return false;
+}
+
 template <int T, int R, bool F>
 static hipError_t launch_wgsym(deff_ctx *c, const SweepPlan &pl, double *xa, double *xb, int npass, unsigned base)
 {
@@ -600,6 +620,7 @@ static int plan_tall(deff_ctx *c, SweepPlan *pl, int T, int own_h, int R)
     TRY(ensure_resident_buffers(c, tiles));
     if (c->tb_sym != 2) TRY(check_links_symmetric(c));            // once per (codes, dictionary): one pass over the codes
     pl->sym = c->tb_sym != 2 && c->links_sym == 1;
+    pl->aged = c->tb_tall_deal && wgage_has(R) && pl->sym && !pl->guard;   // rows dealt by age: k_sweep_wgage
     return DEFF_OK;
 }
 
@@ -874,6 +895,7 @@ static void record_plan(deff_ctx *c, const SweepPlan *pl)
     c->plan_NW = pl->impl == 2 ? pl->NW : 0;
     c->plan_resident = pl->impl == 2 && pl->resident ? 1 : 0;
     c->plan_ranked = pl->impl == 1 && pl->dealt ? 1 : 0;
+    c->plan_aged = pl->impl == 2 && pl->NW == WGL_WAVES && pl->aged ? 1 : 0;
 }
 
 // The form of a blocked pass, in this order ("What the planner picks"): 8-wave tiles when they are all
@@ -1132,6 +1154,15 @@ static int launch_resident_passes(deff_ctx *c, const SweepPlan &pl, int64_t *n)
 #define LAUNCH_WGS(T_, R_, C_) e = launch_wgsym<T_, R_, C_>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch)
             WGS_DISPATCH(pl.T, pl.R, pl.fma, LAUNCH_WGS);
 #undef LAUNCH_WGS
+        } else if (pl.NW == WGL_WAVES && pl.aged) {
+            e = hipErrorInvalidConfiguration;                       // (stays if the table has no set for pl.R: plan_tall asked wgage_has)
+#define X(R_, A_, B_, C_, D_)                                                                                               \
+            if (pl.R == R_) {                                                                                                \
+                if (pl.fma) e = launch_wgage<A_, B_, C_, D_, true, false, true>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch);  \
+                else e = launch_wgage<A_, B_, C_, D_, false, false, true>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch);        \
+            }
+            WGAGE_SETS(X)
+#undef X
         } else if (pl.NW == WGL_WAVES) {
             // (the symmetric short-cut exists in the unguarded kernels only: the guarded one branches on every link anyway)
 #define LAUNCH_WGL(T_, R_, C_, G_) e = launch_wgres<T_, R_, C_, G_, true, false>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch)

@@ -188,6 +188,8 @@ struct deff_ctx {
     // Streaming kernel, chunk heights by service order (deal_ranked_tiles, api_solve.hip): 0 = equal chunks, 1 = dealt tiles.
     // tb_rank_w: the relative speed (per mille) of a SIMD's oldest / second / youngest wave, tb_rank_wall: what a row of a wall strip
     // costs, per mille of an inner strip's (its waves look up b as well)
+    int tb_tall_deal = 1;                        // tall tiles: rows dealt by the waves' age where a kernel for it exists (api_solve.hip, WGAGE_SETS)
+    int plan_aged = 0;
     int tb_ranked = 1;
     int tb_rank_w[3] = {460, 325, 215};
     int tb_rank_wall = 1100;
@@ -309,6 +311,7 @@ struct SweepPlan {
     const int4 *dealt = nullptr;                          // streaming kernel: dealt tiles (chunk heights by service order), or none
     bool resident = false;                                // impl 2 only: all passes of a batch in one launch (k_sweep_wgres)
     bool sym = false;                                     // tall tiles: the system is link-symmetric (7 lookups per row)
+    bool aged = false;                                    // tall tiles: rows dealt by the waves' age (k_sweep_wgage)
     // rows the plan updates: band_h > 0 restricts it to the band [band_lo, band_lo + band_h) of the context's owned rows
     // (input); own_lo / own_h are what the planner resolved (output, passed to the kernels)
     int band_lo = 0, band_h = 0, own_lo = 0, own_h = 0;

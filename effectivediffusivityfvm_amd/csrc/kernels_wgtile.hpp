@@ -741,8 +741,11 @@ __device__ __forceinline__ void wgr_st2(__amdgpu_buffer_rsrc_t r, unsigned voff,
 constexpr int WGF_COEF = 0;     // 8 waves, full matrix rows in registers (20 VGPRs per tile row): any dictionary
 constexpr int WGF_TALL = 1;     // 16 waves, field in registers, codes in LDS, matrix rows looked up in every sweep
 constexpr int WGF_SYM = 2;      // NW waves, link-symmetric matrix rows in registers (14 VGPRs per tile row), unguarded systems
+// (lut, edge, codes_lds: the workgroup's LDS -- dictionary, mailbox, and for tall tiles the codes of every tile row --, declared
+// by the kernel; first: the wave's first row within the tile, wave * R unless the rows are dealt by age, k_sweep_wgage)
 template <int T, int R, int NW, bool FMA, bool GUARD, int FORM, bool SYM>
-__device__ __forceinline__ void wgres_body(const double *__restrict__ lut_g,
+__device__ __forceinline__ void wgres_body(double *lut, double2 (&edge)[2][NW][2][64], unsigned *codes_lds, const int first,
+                                                                   const double *__restrict__ lut_g,
                                                                    const uint16_t *__restrict__ code, double *xa,
                                                                    double *xb, int nx, int ny, int img_stride,
                                                                    int dom_lo, int own_lo, int own_h, int cpi, int ly,
@@ -760,10 +763,6 @@ __device__ __forceinline__ void wgres_body(const double *__restrict__ lut_g,
     static_assert(LUT_PLANES * LUT_MAX_ROWS <= 6 * NW * 64, "dictionary fetch assumes <= 6 doubles per thread");
     constexpr int HW = (T + 1) & ~1;
     constexpr int WOUT = TB_COLS - 2 * HW;
-
-    __shared__ double lut[LUT_DOUBLES];
-    __shared__ double2 edge[2][NW][2][64];
-    __shared__ unsigned codes_lds[TALL ? NW * R * 64 : 1];         // tall tiles: the codes of every tile row
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -786,7 +785,7 @@ __device__ __forceinline__ void wgres_body(const double *__restrict__ lut_g,
     const int ry1 = min(ry0 + ly, own0 + own_h);
     // a tall tile keeps no rows above the first row of its image (there is no halo beyond a wall): its 16R rows then reach
     // T rows further down, which is what lets ONE tile hold a whole 128-row image (api_solve.hip, wgl_row_tiles)
-    const int w0 = (TALL ? max(ry0 - T, row_lo) : ry0 - T) + wave * R;
+    const int w0 = (TALL ? max(ry0 - T, row_lo) : ry0 - T) + first;
     const int ld_lo = max(ry0 - T, row_lo), ld_hi = min(ry1 + T, row_hi);
     const int col = tx * WOUT - shift + 2 * lane;
     const bool in_x = col >= 0 && col < nx;
@@ -826,7 +825,7 @@ __device__ __forceinline__ void wgres_body(const double *__restrict__ lut_g,
         const unsigned vc = *reinterpret_cast<const uint32_t *>(code + p);
         xr[r] = ok ? vx : zero;
         cc[r] = ok ? vc : 0u;
-        if constexpr (TALL) codes_lds[(wave * R + r) * 64 + lane] = cc[r];      // read back by the same lane only
+        if constexpr (TALL) codes_lds[(first + r) * 64 + lane] = cc[r];         // read back by the same lane only
     }
     load_lut<NW * 64>(lut, lut_g, nrows);
 
@@ -888,7 +887,7 @@ __device__ __forceinline__ void wgres_body(const double *__restrict__ lut_g,
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 st[4 * p + 1] = wall_clock64();
             }
-            if constexpr (TALL) wgl_sweeps<T, R, FMA, GUARD, WALL, SYM>(xr, codes_lds + wave * R * 64 + lane, lut, edge, par, wave, lane, w0, ry0, ry1, row_lo, row_hi, omw);
+            if constexpr (TALL) wgl_sweeps<T, R, FMA, GUARD, WALL, SYM>(xr, codes_lds + first * 64 + lane, lut, edge, par, wave, lane, w0, ry0, ry1, row_lo, row_hi, omw);
             else if constexpr (FORM == WGF_SYM) wgs_sweeps<T, R, NW, FMA, WALL>(xr, ks, bb, edge, par, wave, lane, w0, ry0, ry1, row_lo, row_hi, omw);
             else wgt_sweeps<T, R, FMA, GUARD, WALL>(xr, k, bb, edge, par, wave, lane, w0, ry0, ry1, row_lo, row_hi, omw, nullptr);
             if (st && p < 3) st[4 * p + 2] = wall_clock64();
@@ -931,8 +930,12 @@ __global__ __launch_bounds__((TALL ? WGL_WAVES : WGT_WAVES) * 64, (TALL ? 4 : 2)
                                                                    unsigned long long *__restrict__ stamps)
 {
     static_assert(R >= 4, "unsupported tile");
-    wgres_body<T, R, (TALL ? WGL_WAVES : WGT_WAVES), FMA, GUARD, (TALL ? WGF_TALL : WGF_COEF), SYM>(
-        lut_g, code, xa, xb, nx, ny, img_stride, dom_lo, own_lo, own_h, cpi, ly, active, ntx, gy, xmajor, allb, nrows, shift, omw,
+    constexpr int NW = TALL ? WGL_WAVES : WGT_WAVES;
+    __shared__ double lut[LUT_DOUBLES];
+    __shared__ double2 edge[2][NW][2][64];
+    __shared__ unsigned codes_lds[TALL ? NW * R * 64 : 1];         // tall tiles: the codes of every tile row
+    wgres_body<T, R, NW, FMA, GUARD, (TALL ? WGF_TALL : WGF_COEF), SYM>(
+        lut, edge, codes_lds, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * R, lut_g, code, xa, xb, nx, ny, img_stride, dom_lo, own_lo, own_h, cpi, ly, active, ntx, gy, xmajor, allb, nrows, shift, omw,
         npass, flags, base, abort_flag, xbytes, stall_tile, stamps);
 }
 
@@ -949,9 +952,47 @@ __global__ __launch_bounds__(WGS_WAVES * 64, 3) void k_sweep_wgsym(const double 
                                                                    unsigned xbytes, int stall_tile,
                                                                    unsigned long long *__restrict__ stamps)
 {
+    __shared__ double lut[LUT_DOUBLES];
+    __shared__ double2 edge[2][WGS_WAVES][2][64];
+    __shared__ unsigned codes_lds[1];
     wgres_body<T, R, WGS_WAVES, FMA, false, WGF_SYM, true>(
-        lut_g, code, xa, xb, nx, ny, img_stride, dom_lo, own_lo, own_h, cpi, ly, active, ntx, gy, xmajor, allb, nrows, shift, omw,
+        lut, edge, codes_lds, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * R, lut_g, code, xa, xb, nx, ny, img_stride, dom_lo, own_lo, own_h, cpi, ly, active, ntx, gy, xmajor, allb, nrows, shift, omw,
         npass, flags, base, abort_flag, xbytes, stall_tile, stamps);
+}
+
+// Tall tiles with the rows dealt by age.  A tile's waves meet at a barrier in every sweep and the SIMD serves its four waves oldest
+// first (wave w of the workgroup: SIMD w % 4, age w / 4): with R rows each they arrive after 3 150 / 4 050 / 5 040 / 6 350 clocks
+// at 2048^2 (R = 11, profiles/r04_tile_wave_service_order.log).  Here the waves of age 0..3 hold RA >= RB >= RC >= RD rows
+// (RA + RB + RC + RD = 4R: the same tile, the same halo, the same number of tiles) and each age runs the pass loop instantiated
+// for ITS row count -- the row count must be a compile-time constant: a run-time one cost the sweeps their schedule and the
+// field its registers (tools/experiments/r04_tall_rows_by_age_runtime.patch).  All four bodies pass the same barriers.
+template <int T, int RA, int RB, int RC, int RD, bool FMA, bool GUARD, bool SYM>
+__global__ __launch_bounds__(WGL_WAVES * 64, 4) void k_sweep_wgage(const double *__restrict__ lut_g,
+                                                                   const uint16_t *__restrict__ code, double *xa,
+                                                                   double *xb, int nx, int ny, int img_stride,
+                                                                   int dom_lo, int own_lo, int own_h, int cpi, int ly,
+                                                                   const uint8_t *__restrict__ active, int ntx, int gy,
+                                                                   int xmajor, int allb, int nrows, int shift,
+                                                                   double omw, int npass, unsigned *flags,
+                                                                   unsigned base, unsigned *abort_flag,
+                                                                   unsigned xbytes, int stall_tile,
+                                                                   unsigned long long *__restrict__ stamps)
+{
+    static_assert(RA >= RB && RB >= RC && RC >= RD && RD >= 3, "rows by age: oldest first");
+    __shared__ double lut[LUT_DOUBLES];
+    __shared__ double2 edge[2][WGL_WAVES][2][64];
+    __shared__ unsigned codes_lds[4 * (RA + RB + RC + RD) * 64];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int age = wave >> 2, nth = wave & 3;
+#define WGAGE_BODY(R_, FIRST_)                                                                                              \
+    wgres_body<T, R_, WGL_WAVES, FMA, GUARD, WGF_TALL, SYM>(lut, edge, codes_lds, (FIRST_) + nth * R_, lut_g, code, xa, xb, nx, ny,   \
+        img_stride, dom_lo, own_lo, own_h, cpi, ly, active, ntx, gy, xmajor, allb, nrows, shift, omw, npass, flags, base,   \
+        abort_flag, xbytes, stall_tile, stamps)
+    if (age == 0) WGAGE_BODY(RA, 0);
+    else if (age == 1) WGAGE_BODY(RB, 4 * RA);
+    else if (age == 2) WGAGE_BODY(RC, 4 * (RA + RB));
+    else WGAGE_BODY(RD, 4 * (RA + RB + RC));
+#undef WGAGE_BODY
 }
 
 }  // namespace deff

@@ -75,7 +75,7 @@ class Solver:
     def plan(self):
         """What the temporally blocked kernel's last launch plan chose (zeros before any sweep)."""
         out = {}
-        for key in ("tb_T", "tb_LY", "tb_strips", "tb_chunks_per_image", "tb_blocks", "tb_impl", "tb_R", "tb_NW", "tb_resident", "tb_sym", "tb_ranked"):
+        for key in ("tb_T", "tb_LY", "tb_strips", "tb_chunks_per_image", "tb_blocks", "tb_impl", "tb_R", "tb_NW", "tb_resident", "tb_sym", "tb_ranked", "tb_aged"):
             v = C.c_int()
             check(self._L.deff_get_plan(self._ctx, key.encode(), C.byref(v)))
             out[key] = v.value

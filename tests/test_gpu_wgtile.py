@@ -512,6 +512,35 @@ def test_tall_tiles_zero_diffusivity_guard_and_three_phase(pkg, oracle, img00000
         assert_field(s.get_field(), want3)
 
 
+@pytest.mark.parametrize("R", [5, 6, 7, 8, 10, 11, 12])
+def test_tall_tiles_with_rows_dealt_by_age(pkg, oracle, R):
+    """k_sweep_wgage (round 4): the 4R rows of a SIMD's four waves dealt by the waves' age -- each age runs the pass loop
+    instantiated for its own row count, the tile and its halo stay what they were.  Against the oracle and against equal rows,
+    both arithmetics, ragged shapes (tiles cut by the image's bottom edge, one strip narrower than the rest), two launches."""
+    for nx, ny in ((300, 16 * R + 40), (1030, 137), (250, 3 * (16 * R - 16) + 5)):
+        rng = np.random.default_rng(nx + ny + R)
+        pix = rand_mask(rng, nx, ny, 0.5)
+        D = oracle.fill_D_2phase(pix, 1.0, 1e-3)
+        A, b = oracle.discretize(D, 0.0, 1.0)
+        x0 = rng.random((ny, nx))
+        for fma, flavour in ((0, None), (1, "fma")):
+            want1 = oracle.sweeps(A, b, x0, 43, flavour=flavour)
+            want2 = oracle.sweeps(A, b, want1, 16, flavour=flavour)
+            for deal in (1, 0):
+                with pkg.Solver(nx, ny, kernel="matfree_tb") as s:
+                    s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 16); s.set_tuning("tb_R", R); s.set_tuning("fma", fma)
+                    s.set_tuning("tb_tall_deal", deal)
+                    s.set_image(pix)
+                    s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+                    s.set_field(x0)
+                    s.sweeps(43)
+                    p = s.plan()
+                    assert (p["tb_impl"], p["tb_NW"], p["tb_R"], p["tb_resident"], p["tb_aged"]) == (2, 16, R, 1, deal), p
+                    assert np.array_equal(s.get_field(), want1), (nx, ny, fma, deal)
+                    s.sweeps(16)
+                    assert np.array_equal(s.get_field(), want2), (nx, ny, fma, deal)
+
+
 def test_tall_tiles_stack_with_frozen_images(pkg, oracle):
     """A stack on tall tiles: images stop at different checks (their tiles then leave the launch at once)."""
     nx, ny, B = 130, 170, 5

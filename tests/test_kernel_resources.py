@@ -120,6 +120,21 @@ def test_tall_resident_kernel_fits_four_waves_per_simd(usage):
     assert seen == set(budget)
 
 
+def test_aged_tall_kernels_fit_four_waves_per_simd(usage):
+    """k_sweep_wgage<8, RA, RB, RC, RD, FMA, false, true>: four pass loops in one kernel, one per wave age; the registers and the
+    scratch are those of the largest (RA rows), the LDS that of the uniform tile of (RA + RB + RC + RD) / 4 rows per wave."""
+    seen = set()
+    for name, u in usage.items():
+        m = re.match(r"_ZN4deff13k_sweep_wgageILi8ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb[01]ELb0ELb1EEE", name)
+        if not m:
+            continue
+        rows = tuple(int(v) for v in m.groups())
+        seen.add(rows)
+        assert u["Occupancy"] >= 4 and u["VGPRs"] <= 128 and u["AGPRs"] == 0 and u["ScratchSize"] <= 400, (name, u)
+        assert u["LDS"] <= 160 * 1024 and u["LDS"] >= 24 * 1024 + 64 * 1024 + sum(rows) * 4 * 256, (name, u)
+    assert seen == {(6, 6, 5, 3), (8, 8, 5, 3), (8, 8, 8, 4), (9, 9, 9, 5), (12, 12, 10, 6), (13, 13, 11, 7), (13, 13, 13, 9)}
+
+
 def test_symmetric_tile_kernel_fits_three_waves_per_simd(usage):
     """k_sweep_wgsym<8, R, FMA>: 12 waves per workgroup = 3 per SIMD = 168 VGPRs, symmetric matrix rows in registers (14 VGPRs
     per tile row); R = 4, 5 without any scratch (R = 6 would spill inside the sweep loop and is not instantiated);
