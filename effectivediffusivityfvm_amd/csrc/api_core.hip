@@ -272,6 +272,8 @@ try {
     else if (!strcmp(key, "tb_wg")) c->tb_wg = (value + 7) / 8 * 8;
     else if (!strcmp(key, "tb_ranked")) { c->tb_ranked = value ? 1 : 0; c->tb_rank_lost = 0; }
     else if (!strcmp(key, "tb_tall_deal")) c->tb_tall_deal = value ? 1 : 0;
+    else if (!strcmp(key, "tb_sym_age")) c->tb_sym_age = value ? 1 : 0;
+    else if (!strcmp(key, "tb_sym_shape")) c->tb_sym_shape = value;
     else if (!strcmp(key, "tb_rank_w0")) c->tb_rank_w[0] = value;
     else if (!strcmp(key, "tb_rank_w1")) c->tb_rank_w[1] = value;
     else if (!strcmp(key, "tb_rank_w2")) c->tb_rank_w[2] = value;

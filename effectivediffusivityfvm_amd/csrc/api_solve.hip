@@ -629,6 +629,18 @@ static int plan_tall(deff_ctx *c, SweepPlan *pl, int T, int own_h, int R)
 // so wherever the system is verified link-symmetric and unguarded this form replaces the 8-wave tiles: the fewest rows per
 // wave whose tiles all fit the chip.  *R = 0: not applicable (not symmetric, guarded, too many tiles, caller insists on
 // another form).  T = 8, resident launches only.
+// Shapes of a 12-wave tile: the rows of the waves of age 0 / 1 / 2 (wave >> 2: a SIMD serves its three waves oldest first, and
+// a tile's waves meet at a barrier in every sweep -- see k_sweep_wgage).  Equal rows (k_sweep_wgsym<T, R>) for every T; for T = 8
+// also the shapes that give the younger waves a row less (k_sweep_wgsage): 5 / 5 / 4 is a 56-row tile that sweeps ~9 % faster
+// than 5 / 5 / 5 and owns 40 rows instead of 44 -- one 1024^2 image: 234 tiles instead of 216, 853 -> 901 G; 4 / 4 / 3 and 5 / 4 / 4
+// likewise (704^2 ... 992^2: +6 ... 11 %, profiles/r04_sym_shapes_kbench.log).  The planner takes the
+// first shape of this list (fewest rows first) whose tiles all fit the chip.  Encoded for the callers as R | a << 8 | b << 16 |
+// c << 24 (R = the most rows a wave holds; a = 0: equal rows).
+struct SymShape { int a, b, c; bool aged; };
+static const SymShape SYM_SHAPES_T8[] = {{4, 4, 3, true}, {4, 4, 4, false}, {5, 4, 4, true}, {5, 5, 4, true}, {5, 5, 5, false}};
+static const SymShape SYM_SHAPES[] = {{4, 4, 4, false}, {5, 5, 5, false}};
+static int sym_shape_rows(int enc) { return (enc >> 8) ? 4 * (((enc >> 8) & 0xFF) + ((enc >> 16) & 0xFF) + ((enc >> 24) & 0xFF)) : WGS_WAVES * (enc & 0xFF); }
+
 static int choose_sym_R(deff_ctx *c, const SweepPlan *pl, int T, int own_h, int *sym_R)
 {
     *sym_R = 0;
@@ -637,16 +649,23 @@ static int choose_sym_R(deff_ctx *c, const SweepPlan *pl, int T, int own_h, int 
     if (T != 8 && c->tb_T && c->tb_NW != WGS_WAVES) return DEFF_OK;  // a caller's T = 4 / 6 means these tiles only together with tb_NW = 12
     if (c->tb_NW != WGS_WAVES && (c->tb_R != 0 || c->tb_LY != 0)) return DEFF_OK;
     int found = 0;
-    for (int R : WGS_ROWS) {
-        if (c->tb_NW == WGS_WAVES && wgs_has_R(c->tb_R) && R != c->tb_R) continue;
-        const int lymax = wgs_rows_owned(T, R);
+    const bool t8 = T == 8 && c->tb_sym_age;
+    const SymShape *shapes = t8 ? SYM_SHAPES_T8 : SYM_SHAPES;
+    const int nshapes = t8 ? (int)(sizeof SYM_SHAPES_T8 / sizeof SYM_SHAPES_T8[0]) : (int)(sizeof SYM_SHAPES / sizeof SYM_SHAPES[0]);
+    for (int k = 0; k < nshapes; ++k) {
+        const SymShape &sh = shapes[k];
+        const int R = sh.a;
+        if (c->tb_NW == WGS_WAVES && wgs_has_R(c->tb_R) && (R != c->tb_R || sh.aged)) continue;   // a caller's R: equal rows of that many
+        if (t8 && c->tb_sym_shape && k + 1 != c->tb_sym_shape) continue;                          // tests: this shape of SYM_SHAPES_T8 or none
+        const int enc = sh.aged ? (R | sh.a << 8 | sh.b << 16 | sh.c << 24) : R;
+        const int lymax = sym_shape_rows(enc) - 2 * T;
         const int cpi = (own_h + lymax - 1) / lymax;
         const int LY = (own_h + cpi - 1) / cpi;
         if (LY < T && cpi > 1) continue;                            // a tile's halo must end inside its immediate neighbours
         const long tiles = (long)pl->ntx * cpi * c->nimg;
         int res = 0;
         TRY(wgs_resident_blocks(c, T, R, pl->fma, &res));
-        if (((tiles + 7) / 8) * 8 <= res) { found = R; break; }
+        if (((tiles + 7) / 8) * 8 <= res) { found = enc; break; }
     }
     if (!found) return DEFF_OK;
     TRY(check_links_symmetric(c));                                  // once per (codes, dictionary): one pass over the codes
@@ -654,13 +673,14 @@ static int choose_sym_R(deff_ctx *c, const SweepPlan *pl, int T, int own_h, int 
     return DEFF_OK;
 }
 
-static int plan_sym(deff_ctx *c, SweepPlan *pl, int T, int own_h, int R)
+static int plan_sym(deff_ctx *c, SweepPlan *pl, int T, int own_h, int enc)
 {
     pl->impl = 2;
     pl->NW = WGS_WAVES;
-    pl->R = R;
+    pl->R = enc & 0xFF;
+    pl->rows3 = enc >> 8;
     pl->guard = false;
-    const int lymax = wgs_rows_owned(T, R);
+    const int lymax = sym_shape_rows(enc) - 2 * T;
     const int cpi = (own_h + lymax - 1) / lymax;
     pl->LY = (own_h + cpi - 1) / cpi;
     pl->tcpi = (own_h + pl->LY - 1) / pl->LY;
@@ -895,7 +915,7 @@ static void record_plan(deff_ctx *c, const SweepPlan *pl)
     c->plan_NW = pl->impl == 2 ? pl->NW : 0;
     c->plan_resident = pl->impl == 2 && pl->resident ? 1 : 0;
     c->plan_ranked = pl->impl == 1 && pl->dealt ? 1 : 0;
-    c->plan_aged = pl->impl == 2 && pl->NW == WGL_WAVES && pl->aged ? 1 : 0;
+    c->plan_aged = pl->impl == 2 && ((pl->NW == WGL_WAVES && pl->aged) || (pl->NW == WGS_WAVES && pl->rows3)) ? 1 : 0;
 }
 
 // The form of a blocked pass, in this order ("What the planner picks"): 8-wave tiles when they are all
@@ -938,7 +958,7 @@ static int plan_blocked_pass(deff_ctx *c, SweepPlan *pl)
             if (c->tb_NW != WGS_WAVES) {
                 SweepPlan alt = *pl;
                 TRY(plan_tiles8(c, &alt, T, own_h));
-                if (alt.resident && 2 * alt.R * 160 <= 3 * sym_R * 142) { *pl = alt; take_sym = false; }
+                if (alt.resident && 2 * alt.R * 160 <= 3 * (sym_R & 0xFF) * 142) { *pl = alt; take_sym = false; }
             }
             if (take_sym) TRY(plan_sym(c, pl, T, own_h, sym_R));
             planned = true;
@@ -961,7 +981,7 @@ static int plan_blocked_pass(deff_ctx *c, SweepPlan *pl)
                     plan_strips(c, Ts, &alt);
                     int rs = 0;
                     TRY(choose_sym_R(c, &alt, Ts, own_h, &rs));
-                    if (Ts == 4 && rs && rs < 5 && tall_R && tall_R <= 4) rs = 0;      // (4 x 4 rows per sweep: no better than tall R = 4)
+                    if (Ts == 4 && rs && (rs & 0xFF) < 5 && tall_R && tall_R <= 4) rs = 0;      // (4 x 4 rows per sweep: no better than tall R = 4)
                     if (rs) { TRY(plan_sym(c, &alt, Ts, own_h, rs)); *pl = alt; shorter = true; break; }
                 }
             }
@@ -1150,7 +1170,16 @@ static int launch_resident_passes(deff_ctx *c, const SweepPlan &pl, int64_t *n)
             c->res_epoch = 0;
         }
         hipError_t e = hipSuccess;
-        if (pl.NW == WGS_WAVES) {
+        if (pl.NW == WGS_WAVES && pl.rows3) {
+            e = hipErrorInvalidConfiguration;                       // (stays if SYM_SHAPES_T8 names a shape without a kernel)
+#define SAGE(A_, B_, C_)                                                                                                    \
+            if (pl.T == 8 && pl.rows3 == (A_ | B_ << 8 | C_ << 16)) {                                                        \
+                if (pl.fma) e = launch_resident(c, pl, k_sweep_wgsage<8, A_, B_, C_, true>, WGS_WAVES * 64, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch);  \
+                else e = launch_resident(c, pl, k_sweep_wgsage<8, A_, B_, C_, false>, WGS_WAVES * 64, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch);        \
+            }
+            SAGE(4, 4, 3) SAGE(5, 4, 4) SAGE(5, 5, 4)
+#undef SAGE
+        } else if (pl.NW == WGS_WAVES) {
 #define LAUNCH_WGS(T_, R_, C_) e = launch_wgsym<T_, R_, C_>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch)
             WGS_DISPATCH(pl.T, pl.R, pl.fma, LAUNCH_WGS);
 #undef LAUNCH_WGS

@@ -190,6 +190,8 @@ struct deff_ctx {
     // costs, per mille of an inner strip's (its waves look up b as well)
     int tb_tall_deal = 1;                        // tall tiles: rows dealt by the waves' age where a kernel for it exists (api_solve.hip, WGAGE_SETS)
     int plan_aged = 0;
+    int tb_sym_age = 1;                          // 12-wave tiles: the shapes with a row less for the youngest waves (api_solve.hip, SYM_SHAPES_T8)
+    int tb_sym_shape = 0;                        // tests: 1-based index into SYM_SHAPES_T8 (0: the planner's choice)
     int tb_ranked = 1;
     int tb_rank_w[3] = {460, 325, 215};
     int tb_rank_wall = 1100;
@@ -312,6 +314,7 @@ struct SweepPlan {
     bool resident = false;                                // impl 2 only: all passes of a batch in one launch (k_sweep_wgres)
     bool sym = false;                                     // tall tiles: the system is link-symmetric (7 lookups per row)
     bool aged = false;                                    // tall tiles: rows dealt by the waves' age (k_sweep_wgage)
+    int rows3 = 0;                                        // 12-wave tiles: rows by age, a | b << 8 | c << 16 (0: R each)
     // rows the plan updates: band_h > 0 restricts it to the band [band_lo, band_lo + band_h) of the context's owned rows
     // (input); own_lo / own_h are what the planner resolved (output, passed to the kernels)
     int band_lo = 0, band_h = 0, own_lo = 0, own_h = 0;

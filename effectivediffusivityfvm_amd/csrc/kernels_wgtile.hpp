@@ -995,4 +995,33 @@ __global__ __launch_bounds__(WGL_WAVES * 64, 4) void k_sweep_wgage(const double 
 #undef WGAGE_BODY
 }
 
+// The link-symmetric form with the rows dealt by age (three waves per SIMD: ages 0..2), as k_sweep_wgage.
+template <int T, int RA, int RB, int RC, bool FMA>
+__global__ __launch_bounds__(WGS_WAVES * 64, 3) void k_sweep_wgsage(const double *__restrict__ lut_g,
+                                                                   const uint16_t *__restrict__ code, double *xa,
+                                                                   double *xb, int nx, int ny, int img_stride,
+                                                                   int dom_lo, int own_lo, int own_h, int cpi, int ly,
+                                                                   const uint8_t *__restrict__ active, int ntx, int gy,
+                                                                   int xmajor, int allb, int nrows, int shift,
+                                                                   double omw, int npass, unsigned *flags,
+                                                                   unsigned base, unsigned *abort_flag,
+                                                                   unsigned xbytes, int stall_tile,
+                                                                   unsigned long long *__restrict__ stamps)
+{
+    static_assert(RA >= RB && RB >= RC && RC >= 3, "rows by age: oldest first");
+    __shared__ double lut[LUT_DOUBLES];
+    __shared__ double2 edge[2][WGS_WAVES][2][64];
+    __shared__ unsigned codes_lds[1];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int age = wave >> 2, nth = wave & 3;
+#define WGSAGE_BODY(R_, FIRST_)                                                                                             \
+    wgres_body<T, R_, WGS_WAVES, FMA, false, WGF_SYM, true>(lut, edge, codes_lds, (FIRST_) + nth * R_, lut_g, code, xa, xb, nx, ny,   \
+        img_stride, dom_lo, own_lo, own_h, cpi, ly, active, ntx, gy, xmajor, allb, nrows, shift, omw, npass, flags, base,   \
+        abort_flag, xbytes, stall_tile, stamps)
+    if (age == 0) WGSAGE_BODY(RA, 0);
+    else if (age == 1) WGSAGE_BODY(RB, 4 * RA);
+    else WGSAGE_BODY(RC, 4 * (RA + RB));
+#undef WGSAGE_BODY
+}
+
 }  // namespace deff

@@ -805,6 +805,50 @@ def test_sym_tiles_with_passes_of_six_and_four_sweeps_vs_oracle(pkg, oracle, sha
             assert np.array_equal(s.get_field(), want2)
 
 
+@pytest.mark.parametrize("shape_no,rows", [(1, (4, 4, 3)), (3, (5, 4, 4)), (4, (5, 5, 4))])
+@pytest.mark.parametrize("size", [(300, 200), (1030, 137), (250, 333), (2, 64), (97, 241)])
+def test_sym_tiles_with_rows_dealt_by_age(pkg, oracle, size, shape_no, rows):
+    """k_sweep_wgsage<8, a, b, c> (round 4): the link-symmetric tiles with a row less for the younger waves of a SIMD -- tiles of
+    4 (a + b + c) rows, each age on the pass loop instantiated for its own row count.  Ragged strips and row tiles, both
+    arithmetics, omega 2/3 and 1; 45 = 5 passes + 5 single sweeps, then 13 more in a second launch."""
+    nx, ny = size
+    rng = np.random.default_rng(nx * 13 + ny * 7 + shape_no)
+    pix = rand_mask(rng, nx, ny, 0.5)
+    D = oracle.fill_D_2phase(pix, 1.0, 1e-3)
+    A, b = oracle.discretize(D, 0.0, 1.0)
+    x0 = rng.random((ny, nx))
+    owned = 4 * sum(rows) - 16
+    for omega, kern, flavour, fma in ((2.0 / 3.0, 0, None, 0), (1.0, 1, None, 0), (2.0 / 3.0, 0, "fma", 1)):
+        want1 = oracle.sweeps(A, b, x0, 45, kernel=kern, omega=omega, flavour=flavour)
+        want2 = oracle.sweeps(A, b, want1, 13, kernel=kern, omega=omega, flavour=flavour)
+        with pkg.Solver(nx, ny, kernel="matfree_tb") as s:
+            s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 12); s.set_tuning("tb_sym_shape", shape_no); s.set_tuning("fma", fma)
+            s.set_image(pix)
+            s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            s.set_field(x0)
+            s.sweeps(45, omega)
+            p = s.plan()
+            assert (p["tb_impl"], p["tb_NW"], p["tb_R"], p["tb_T"], p["tb_resident"], p["tb_sym"], p["tb_aged"]) == (2, 12, rows[0], 8, 1, 1, 1), p
+            assert 1 <= p["tb_LY"] <= owned and p["tb_LY"] * p["tb_chunks_per_image"] >= ny
+            assert np.array_equal(s.get_field(), want1)
+            s.sweeps(13, omega)
+            assert np.array_equal(s.get_field(), want2)
+
+
+def test_planner_takes_the_smallest_tile_shape_that_fits(pkg):
+    """12-wave tiles, T = 8: 4/4/3, 4/4/4, 5/4/4, 5/5/4, 5/5/5 rows by age -- the first whose tiles are all on the chip."""
+    for n, rows_first, tiles in ((896, 4, 256), (992, 5, 252), (1024, 5, 234), (1088, 5, 250)):
+        with pkg.Solver(n, n) as s:
+            s.synth_image(3, 0)
+            s.assemble_2phase(1e-3, 1.0, 0.0, 1.0)
+            s.init_linear(0.0, 1.0)
+            s.sweeps(16)
+            p = s.plan()
+            assert (p["tb_impl"], p["tb_NW"], p["tb_R"], p["tb_T"], p["tb_resident"]) == (2, 12, rows_first, 8, 1), (n, p)
+            assert p["tb_strips"] * p["tb_chunks_per_image"] == tiles, (n, p)
+            assert p["tb_aged"] == (0 if n == 1088 else 1), (n, p)          # 1088^2 only fits with equal rows of 5
+
+
 def test_planner_takes_passes_of_six_where_eight_do_not_fit(pkg, oracle):
     """1152^2 -- 9 x 128 columns, the worst point of round 3's size curve (648-672 G on tall tiles) -- is 27 x 11 = 297 tiles of the
     12-wave form at T = 8 and 24 x 10 = 240 at T = 6: the planner takes the latter on its own, a solve's 10 000-sweep intervals

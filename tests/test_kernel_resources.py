@@ -150,6 +150,19 @@ def test_symmetric_tile_kernel_fits_three_waves_per_simd(usage):
     assert seen == {(8, 4), (8, 5), (6, 4), (6, 5), (4, 4), (4, 5)}          # passes of 8 sweeps and (round 4) of 6 and 4
 
 
+def test_aged_symmetric_tile_kernels_fit_three_waves_per_simd(usage):
+    """k_sweep_wgsage<8, a, b, c, FMA>: three pass loops in one kernel (one per wave age), 168 VGPRs, no scratch."""
+    seen = set()
+    for name, u in usage.items():
+        m = re.match(r"_ZN4deff14k_sweep_wgsageILi8ELi(\d+)ELi(\d+)ELi(\d+)ELb[01]EEE", name)
+        if not m:
+            continue
+        seen.add(tuple(int(v) for v in m.groups()))
+        assert u["Occupancy"] >= 3 and u["VGPRs"] <= 168 and u["AGPRs"] == 0 and u["ScratchSize"] == 0, (name, u)
+        assert u["LDS"] <= 80 * 1024, (name, u)
+    assert seen == {(4, 4, 3), (5, 4, 4), (5, 5, 4)}
+
+
 def test_single_sweep_kernels_are_light(usage):
     for prefix in ("_ZN4deff16k_sweep_explicitI", "_ZN4deff15k_sweep_matfreeI", "_ZN4deff14k_sweep_scalarI"):
         for name, u in kernels(usage, prefix).items():
