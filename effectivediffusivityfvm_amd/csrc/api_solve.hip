@@ -298,8 +298,8 @@ static hipError_t launch_wgage(deff_ctx *c, const SweepPlan &pl, double *xa, dou
 // Rows by age for the tall tiles of R rows per wave (k_sweep_wgage): the 4R rows of a SIMD's four waves, oldest first.  Measured,
 // not derived (profiles/r04_tall_rows_by_age_kbench.log: four candidate sets per R, one process, against equal rows): what wins
 // gives the youngest wave about half its share and keeps the three older ones level; bodies of 9 and more rows spill, which is why
-// R = 7 stops at 8 rows and R = 9 and 13 found no set that beats equal rows (14 x 4 has nothing to deal).  Link-symmetric,
-// unguarded systems only (the 2-phase assembly and what tb_sym verifies), both arithmetics.
+// R = 7 stops at 8 rows and R = 9 and 13 found no set that beats equal rows (14 x 4 has nothing to deal).  Unguarded systems,
+// link-symmetric (7 lookups per row) or not (10: the 3-phase assembly with impermeable solid), both arithmetics.
 #define WGAGE_SETS(X) X(5, 6, 6, 5, 3) X(6, 8, 8, 5, 3) X(7, 8, 8, 8, 4) X(8, 9, 9, 9, 5) X(10, 12, 12, 10, 6) X(11, 13, 13, 11, 7) X(12, 13, 13, 13, 9)
 static bool wgage_has(int R)
 {
@@ -620,7 +620,7 @@ static int plan_tall(deff_ctx *c, SweepPlan *pl, int T, int own_h, int R)
     TRY(ensure_resident_buffers(c, tiles));
     if (c->tb_sym != 2) TRY(check_links_symmetric(c));            // once per (codes, dictionary): one pass over the codes
     pl->sym = c->tb_sym != 2 && c->links_sym == 1;
-    pl->aged = c->tb_tall_deal && wgage_has(R) && pl->sym && !pl->guard;   // rows dealt by age: k_sweep_wgage
+    pl->aged = c->tb_tall_deal && wgage_has(R) && !pl->guard;     // rows dealt by age: k_sweep_wgage (unguarded systems, symmetric or not)
     return DEFF_OK;
 }
 
@@ -1187,8 +1187,13 @@ static int launch_resident_passes(deff_ctx *c, const SweepPlan &pl, int64_t *n)
             e = hipErrorInvalidConfiguration;                       // (stays if the table has no set for pl.R: plan_tall asked wgage_has)
 #define X(R_, A_, B_, C_, D_)                                                                                               \
             if (pl.R == R_) {                                                                                                \
-                if (pl.fma) e = launch_wgage<A_, B_, C_, D_, true, false, true>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch);  \
-                else e = launch_wgage<A_, B_, C_, D_, false, false, true>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch);        \
+                if (pl.sym) {                                                                                                \
+                    if (pl.fma) e = launch_wgage<A_, B_, C_, D_, true, false, true>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch);  \
+                    else e = launch_wgage<A_, B_, C_, D_, false, false, true>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch);        \
+                } else {                                                                                                     \
+                    if (pl.fma) e = launch_wgage<A_, B_, C_, D_, true, false, false>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch); \
+                    else e = launch_wgage<A_, B_, C_, D_, false, false, false>(c, pl, c->x[c->cur], c->x[c->cur ^ 1], chunk, c->res_epoch);       \
+                }                                                                                                            \
             }
             WGAGE_SETS(X)
 #undef X

@@ -541,6 +541,32 @@ def test_tall_tiles_with_rows_dealt_by_age(pkg, oracle, R):
                     assert np.array_equal(s.get_field(), want2), (nx, ny, fma, deal)
 
 
+def test_tall_tiles_with_rows_dealt_by_age_on_a_system_that_is_not_link_symmetric(pkg, oracle):
+    """The 3-phase assembly with impermeable solid (identity rows carry +0 links, their neighbours -0: not bit-symmetric, ten
+    lookups per row) on the reference's own 00042.jpg, cropped: k_sweep_wgage's SYM = false variant against the oracle."""
+    import os
+    from conftest import ROOT
+    full = pkg.load_jpeg_gray(os.path.join(ROOT, "tests", "golden", "00042.jpg"))
+    pix = np.ascontiguousarray(full[:700, :600])
+    ny, nx = pix.shape
+    grid, _ = oracle.floodfill((pix > 200).astype(np.uint32))
+    D = oracle.fill_D_3phase(pix, 1.0, 0.0, 1237500.0)
+    with np.errstate(all="ignore"):
+        A, b = oracle.discretize(D, 0.0, 1.0, grid=grid)
+        want = oracle.sweeps(A, b, oracle.linear_guess(nx, ny, 0.0, 1.0), 37)
+    for deal in (1, 0):
+        with pkg.Solver(nx, ny) as s:
+            s.set_tuning("tb_impl", 2); s.set_tuning("tb_NW", 16); s.set_tuning("tb_R", 6); s.set_tuning("tb_tall_deal", deal)
+            s.set_image(pix)
+            s.assemble_3phase(0.0, 1.0, 1237500.0, 0.0, 1.0, grid)
+            s.init_linear(0.0, 1.0)
+            s.sweeps(37)
+            p = s.plan()
+            assert s.kernel_in_use() == "matfree_tb"
+            assert (p["tb_NW"], p["tb_R"], p["tb_resident"], p["tb_sym"], p["tb_aged"]) == (16, 6, 1, 2, deal), p
+            assert np.array_equal(s.get_field(), want, equal_nan=True)
+
+
 def test_tall_tiles_stack_with_frozen_images(pkg, oracle):
     """A stack on tall tiles: images stop at different checks (their tiles then leave the launch at once)."""
     nx, ny, B = 130, 170, 5

@@ -121,11 +121,11 @@ def test_tall_resident_kernel_fits_four_waves_per_simd(usage):
 
 
 def test_aged_tall_kernels_fit_four_waves_per_simd(usage):
-    """k_sweep_wgage<8, RA, RB, RC, RD, FMA, false, true>: four pass loops in one kernel, one per wave age; the registers and the
+    """k_sweep_wgage<8, RA, RB, RC, RD, FMA, false, SYM>: four pass loops in one kernel, one per wave age; the registers and the
     scratch are those of the largest (RA rows), the LDS that of the uniform tile of (RA + RB + RC + RD) / 4 rows per wave."""
     seen = set()
     for name, u in usage.items():
-        m = re.match(r"_ZN4deff13k_sweep_wgageILi8ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb[01]ELb0ELb1EEE", name)
+        m = re.match(r"_ZN4deff13k_sweep_wgageILi8ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb[01]ELb0ELb[01]EEE", name)
         if not m:
             continue
         rows = tuple(int(v) for v in m.groups())
