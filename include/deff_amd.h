@@ -81,7 +81,8 @@ int deff_get_kernel(const deff_ctx *ctx, int *kernel_in_use);
 /* tuning knob; 0 restores the default.  Keys: "rows_explicit", "rows_matfree", "wg_matfree",
  * "nt_explicit", "serpentine", "tb_T" (sweeps per pass: 1,2,4,6,8), "tb_LY" (rows per chunk), "tb_wg",
  * "tb_xmajor", "tb_wall_halo", "tb_ranked" (streaming kernel: chunk heights by the service order of a SIMD's waves, 1 default;
- * weights "tb_rank_w0", "tb_rank_w1", "tb_rank_w2", "tb_rank_wall" per mille), "dict" (harvest a row dictionary from explicit systems: 1 default),
+ * weights "tb_rank_w0", "tb_rank_w1", "tb_rank_w2", "tb_rank_wall" per mille), "tb_tall_deal" / "tb_sym_age" (resident tiles: rows
+ * dealt by the waves' age, 1 default), "dict" (harvest a row dictionary from explicit systems: 1 default),
  * "tb_impl" (1 streaming, 2 workgroup tiles), "tb_R", "tb_NW" (8 / 12 / 16 waves per
  *   tile: 12 = link-symmetric matrix rows in registers, 16 = tall resident tiles),
  * "tb_launch" (workgroup tiles whose tiles all fit the chip
