@@ -70,7 +70,9 @@ def test_too_few_gpus_is_reported_by_the_ranks():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=_env(),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
-    assert f"rank 1: device 1 of {ndev}" in r.stderr, r.stderr
+    import re
+    # (whichever rank gets to say it first: torchrun stops the other ranks as soon as one has failed)
+    assert re.search(rf"bench\.py rank [01]: device [01] of {ndev} ", r.stderr), r.stderr
     assert "must be launched with" not in r.stderr
 
 
