@@ -512,7 +512,7 @@ def test_tall_tiles_zero_diffusivity_guard_and_three_phase(pkg, oracle, img00000
         assert_field(s.get_field(), want3)
 
 
-@pytest.mark.parametrize("R", [5, 6, 7, 8, 10, 11, 12])
+@pytest.mark.parametrize("R", [5, 6, 7, 8, 9, 10, 11, 12])
 def test_tall_tiles_with_rows_dealt_by_age(pkg, oracle, R):
     """k_sweep_wgage (round 4): the 4R rows of a SIMD's four waves dealt by the waves' age -- each age runs the pass loop
     instantiated for its own row count, the tile and its halo stay what they were.  Against the oracle and against equal rows,
